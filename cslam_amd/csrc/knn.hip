@@ -1,0 +1,754 @@
+// knn.hip — descriptor pool + brute-force cosine kNN for gfx950 (MI355X).
+//
+// Replaces cslam/nns_matching.py:5-78 (NearestNeighborsMatching): `add_item` → cslam_pool_add*,
+// `search`/`search_best` → cslam_pool_search*.  Numeric contract: DESIGN.md §3 (identical to
+// oracle/knn_oracle.c): dot(x,q) is ONE fmaf chain in v_mfma_f32_16x16x4_f32 operand order,
+// ||x||^2 is a wave64 butterfly sum cached at add time, sim = (dot * rn(x)) * rn(q).
+//
+// Kernels
+//   k_inv_norm      one wave per row, 16-B coalesced loads, xor-butterfly reduce
+//   k_stage_queries pads the query block to [16*T][dp] in HBM (L2-resident) + 1/||q||
+//   k_scan<T,U>     HBM-bound streaming scan: every wave owns a contiguous, byte-balanced row
+//                   range, walks it in 16-row strips, A operand straight from HBM to VGPRs
+//                   (U float4 deep, double-buffered), B operand (queries) from L2,
+//                   fp32 MFMA 16x16x4, epilogue scales by the cached inverse norms
+//   k_select<...>   exact top-k (k <= 128): per-part k rounds of block arg-max on
+//                   (similarity desc, row asc) composites, wave-shuffle + LDS reduction
+//   k_bitonic_step  any k: full bitonic sort of the composites in HBM (rare path)
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace cslam;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kSelectPart = 4096;  // elements per select block (256 threads x 16)
+constexpr int kSelectMaxK = 128;   // above this the bitonic path is used
+constexpr int kMaxQueriesPerPass = 64;
+constexpr int64_t kQueryChunk = 256;  // queries per similarity workspace chunk
+
+__host__ __device__ inline int64_t pad16(int64_t d) { return (d + 15) / 16 * 16; }
+
+// ---------------------------------------------------------------------------------------------
+// composites: (orderable(sim) << 32) | (0xFFFFFFFF - row)  → max = best similarity, lowest row
+// ---------------------------------------------------------------------------------------------
+__device__ inline uint32_t f2ord(float s) {
+    if (s == 0.0f) s = 0.0f;  // -0 → +0
+    uint32_t u = __float_as_uint(s);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ inline float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+    return __uint_as_float(u);
+}
+__device__ inline uint64_t make_comp(float s, uint32_t row) {
+    return ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1 / max(||row||, 1e-8), wave64 order (oracle/knn_oracle.c: sumsq_wave_order)
+// ---------------------------------------------------------------------------------------------
+__device__ inline float wave_sumsq(const float* row, int dp, int lane) {
+    float acc = 0.0f;
+    for (int base = 4 * lane; base < dp; base += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + base);
+        acc = __builtin_fmaf(v.x, v.x, acc);
+        acc = __builtin_fmaf(v.y, v.y, acc);
+        acc = __builtin_fmaf(v.z, v.z, acc);
+        acc = __builtin_fmaf(v.w, v.w, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+    return acc;
+}
+
+__device__ inline float inv_norm_from_sumsq(float ss) {
+    float nrm = __fsqrt_rn(ss);
+    if (!(nrm > 1e-8f)) nrm = 1e-8f;
+    return __fdiv_rn(1.0f, nrm);
+}
+
+__global__ __launch_bounds__(256) void k_inv_norm(const float* __restrict__ rows, int64_t stride,
+                                                  int64_t first, int64_t count, int dp,
+                                                  float* __restrict__ out) {
+    int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (w >= count) return;
+    int64_t r = first + w;
+    float ss = wave_sumsq(rows + r * stride, dp, lane);
+    if (lane == 0) out[r] = inv_norm_from_sumsq(ss);
+}
+
+// copy `count` rows of `dim` floats (stride src_stride) into the padded pool layout
+__global__ __launch_bounds__(256) void k_copy_pad(const float* __restrict__ src,
+                                                  int64_t src_stride, int dim,
+                                                  float* __restrict__ dst, int64_t dst_stride,
+                                                  int dp, int64_t count) {
+    int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (w >= count) return;
+    const float* s = src + w * src_stride;
+    float* d = dst + w * dst_stride;
+    for (int k = lane; k < dp; k += 64) d[k] = (k < dim) ? s[k] : 0.0f;
+}
+
+// queries → staging [mq_pad][dp] (zero padded, rows >= m are zero) and rnq[mq_pad]
+__global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__ q,
+                                                       int64_t q_stride, int dim, int m,
+                                                       int mq_pad, int dp,
+                                                       float* __restrict__ stage,
+                                                       float* __restrict__ rnq) {
+    int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (w >= mq_pad) return;
+    float* d = stage + (int64_t)w * dp;
+    if (w < m) {
+        const float* s = q + (int64_t)w * q_stride;
+        for (int k = lane; k < dp; k += 64) d[k] = (k < dim) ? s[k] : 0.0f;
+    } else {
+        for (int k = lane; k < dp; k += 64) d[k] = 0.0f;
+    }
+    // ||q||^2 straight from the source values, in the same wave64 order as wave_sumsq
+    float ss = 0.0f;
+    if (w < m) {
+        const float* s = q + (int64_t)w * q_stride;
+        for (int base = 4 * lane; base < dp; base += 256) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int k = base + c;
+                float v = (k < dim) ? s[k] : 0.0f;
+                ss = __builtin_fmaf(v, v, ss);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, kWave);
+    }
+    if (lane == 0) rnq[w] = (w < m) ? inv_norm_from_sumsq(ss) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan: sims[q][row] for a block of 16*T staged queries against rows [0,n)
+//   grid: W waves (4 per block); wave w owns rows [w*n/W, (w+1)*n/W)
+//   lane l: r = l & 15 (row in strip / query column), g = l >> 4 (k slot)
+//   A = X[row r][kb + 4g .. +3], B = Q[col r][kb + 4g .. +3]; MFMA j consumes component j
+//   → chain order inside a 16-block: k = kb + 4g + j, j outer, g inner
+// ---------------------------------------------------------------------------------------------
+template <int T, int U>
+__global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64_t xs, int64_t n,
+                                              int dp, const float* __restrict__ Q,
+                                              const float* __restrict__ rnx,
+                                              const float* __restrict__ rnq, int m_valid,
+                                              float* __restrict__ sims, int64_t sims_stride,
+                                              int64_t n_waves) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int64_t lo = (w * n) / n_waves;
+    const int64_t hi = ((w + 1) * n) / n_waves;
+    const int nkb = dp >> 4;            // 16-float k blocks
+    const int nchunk = nkb / U;         // full chunks of U k-blocks
+    const int ktail = nchunk * U;       // first k-block of the tail
+
+    const f32x4* qp[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        qp[t] = reinterpret_cast<const f32x4*>(Q + (int64_t)(t * 16 + r) * dp + 4 * g);
+
+    for (int64_t r0 = lo; r0 < hi; r0 += 16) {
+        int64_t row = r0 + r;
+        if (row >= hi) row = hi - 1;  // clamp: duplicates hit L1, results are not stored
+        const f32x4* xp = reinterpret_cast<const f32x4*>(X + row * xs + 4 * g);
+
+        f32x4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        f32x4 a_cur[U], a_nxt[U];
+        if (nchunk > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) a_cur[u] = xp[u * 4];
+        }
+        for (int c = 0; c < nchunk; ++c) {
+            const int kb0 = c * U;
+            if (c + 1 < nchunk) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) a_nxt[u] = xp[(kb0 + U + u) * 4];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 b[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) b[t] = qp[t][(kb0 + u) * 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j], b[t][j],
+                                                                      acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) a_cur[u] = a_nxt[u];
+        }
+        for (int kb = ktail; kb < nkb; ++kb) {
+            f32x4 a = xp[kb * 4];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 b = qp[t][kb * 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+            }
+        }
+
+        // epilogue: lane holds D[row = 4g + reg][col = r]
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int q = t * 16 + r;
+            if (q < m_valid) {
+                const float sq = rnq[q];
+                float* out = sims + (int64_t)q * sims_stride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int64_t orow = r0 + 4 * g + e;
+                    if (orow < hi) {
+                        float s = (acc[t][e] * rnx[orow]) * sq;
+                        if (s == 0.0f) s = 0.0f;
+                        out[orow] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact top-k by rounds of block arg-max over composites
+// ---------------------------------------------------------------------------------------------
+template <bool FROM_SIMS, bool FINAL>
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
+                                                int64_t sims_stride,
+                                                const uint64_t* __restrict__ cin,
+                                                int64_t cin_stride, int64_t n_in, int k,
+                                                uint64_t* __restrict__ cout, int64_t cout_stride,
+                                                int32_t* __restrict__ out_idx,
+                                                float* __restrict__ out_sim) {
+    __shared__ uint64_t wmax[2][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t q = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * kSelectPart;
+
+    uint64_t v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int64_t i = base + e * 256 + tid;
+        uint64_t c = 0;
+        if (i < n_in) {
+            if (FROM_SIMS)
+                c = make_comp(sims[q * sims_stride + i], (uint32_t)i);
+            else
+                c = cin[q * cin_stride + i];
+        }
+        v[e] = c;
+    }
+
+    for (int rd = 0; rd < k; ++rd) {
+        uint64_t m = v[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) m = v[e] > m ? v[e] : m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            uint64_t o = __shfl_xor(m, off, kWave);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) wmax[rd & 1][wave] = m;
+        __syncthreads();
+        uint64_t win = wmax[rd & 1][0];
+#pragma unroll
+        for (int x = 1; x < 4; ++x) {
+            uint64_t o = wmax[rd & 1][x];
+            win = o > win ? o : win;
+        }
+        if (win != 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (v[e] == win) v[e] = 0;
+        }
+        if (tid == 0) {
+            if (FINAL) {
+                if (win != 0) {
+                    out_idx[q * k + rd] = (int32_t)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu));
+                    out_sim[q * k + rd] = ord2f((uint32_t)(win >> 32));
+                } else {
+                    out_idx[q * k + rd] = -1;
+                    out_sim[q * k + rd] = -INFINITY;
+                }
+            } else {
+                cout[q * cout_stride + (int64_t)blockIdx.x * k + rd] = win;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// any-k path: bitonic sort of composites (descending) in HBM
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_make_comp(const float* __restrict__ sims,
+                                                   int64_t sims_stride, int64_t n, int64_t npow2,
+                                                   uint64_t* __restrict__ comp) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t q = blockIdx.y;
+    if (i >= npow2) return;
+    comp[q * npow2 + i] = (i < n) ? make_comp(sims[q * sims_stride + i], (uint32_t)i) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_bitonic_step(uint64_t* __restrict__ comp, int64_t npow2,
+                                                      int64_t size, int64_t stride) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t q = blockIdx.y;
+    if (i >= npow2 / 2) return;
+    int64_t pos = 2 * i - (i & (stride - 1));
+    uint64_t* p = comp + q * npow2;
+    uint64_t a = p[pos], b = p[pos + stride];
+    bool desc = (pos & size) == 0;
+    if (desc ? (a < b) : (a > b)) {
+        p[pos] = b;
+        p[pos + stride] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_sorted(const uint64_t* __restrict__ comp,
+                                                     int64_t npow2, int k,
+                                                     int32_t* __restrict__ out_idx,
+                                                     float* __restrict__ out_sim) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t q = blockIdx.y;
+    if (j >= k) return;
+    uint64_t c = (j < npow2) ? comp[q * npow2 + j] : 0ull;
+    if (c != 0) {
+        out_idx[q * k + j] = (int32_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFu));
+        out_sim[q * k + j] = ord2f((uint32_t)(c >> 32));
+    } else {
+        out_idx[q * k + j] = -1;
+        out_sim[q * k + j] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __restrict__ out_idx,
+                                                    float* __restrict__ out_sim) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    out_idx[j] = -1;
+    out_sim[j] = -INFINITY;
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct cslam_pool {
+    int dim = 0, dp = 0, device = 0, cus = 256;
+    int64_t n = 0, cap = 0;
+    float* rows = nullptr;      // [cap][dp]
+    float* inv_norm = nullptr;  // [cap]
+    hipStream_t stream = nullptr;
+    DevBuf qstage, rnq, sims, cand_a, cand_b, comp;
+    DevBuf h_q, h_idx, h_sim;  // device staging of the host-pointer API
+    // profiling of the scan kernel
+    std::vector<hipEvent_t> ev;
+    int prof_max = 0, prof_n = 0;
+    bool prof_on = false;
+};
+
+namespace {
+
+int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
+    if (want_rows <= p->cap) return CSLAM_OK;
+    int64_t ncap = p->cap > 0 ? p->cap : 1000;
+    while (ncap < want_rows) ncap *= 2;  // nns_matching.py:38 doubles
+    float* nrows = nullptr;
+    float* nnorm = nullptr;
+    CSLAM_HIP_TRY(hipMalloc(&nrows, (size_t)ncap * p->dp * sizeof(float)));
+    CSLAM_HIP_TRY(hipMalloc(&nnorm, (size_t)ncap * sizeof(float)));
+    if (p->n > 0) {
+        CSLAM_HIP_TRY(hipMemcpyAsync(nrows, p->rows, (size_t)p->n * p->dp * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+        CSLAM_HIP_TRY(hipMemcpyAsync(nnorm, p->inv_norm, (size_t)p->n * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+    }
+    CSLAM_HIP_TRY(hipMemsetAsync(nrows + p->n * p->dp, 0,
+                                 (size_t)(ncap - p->n) * p->dp * sizeof(float), st));
+    CSLAM_HIP_TRY(hipMemsetAsync(nnorm + p->n, 0, (size_t)(ncap - p->n) * sizeof(float), st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    if (p->rows) CSLAM_HIP_TRY(hipFree(p->rows));
+    if (p->inv_norm) CSLAM_HIP_TRY(hipFree(p->inv_norm));
+    p->rows = nrows;
+    p->inv_norm = nnorm;
+    p->cap = ncap;
+    return CSLAM_OK;
+}
+
+int launch_norms(cslam_pool* p, int64_t first, int64_t count, hipStream_t st) {
+    if (count <= 0) return CSLAM_OK;
+    unsigned blocks = (unsigned)((count + 3) / 4);
+    hipLaunchKernelGGL(k_inv_norm, dim3(blocks), dim3(256), 0, st, p->rows, (int64_t)p->dp, first,
+                       count, p->dp, p->inv_norm);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+template <int T, int U>
+void launch_scan_t(cslam_pool* p, const float* Q, const float* rnq, int m_valid, float* sims,
+                   int64_t sims_stride, int64_t n_waves, hipStream_t st) {
+    unsigned blocks = (unsigned)((n_waves + 3) / 4);
+    hipLaunchKernelGGL((k_scan<T, U>), dim3(blocks), dim3(256), 0, st, p->rows, (int64_t)p->dp,
+                       p->n, p->dp, Q, p->inv_norm, rnq, m_valid, sims, sims_stride, n_waves);
+}
+
+// similarities of `m` staged queries (m <= 64) → sims[q*stride + row]
+int launch_scan(cslam_pool* p, const float* Qstage, const float* rnq, int m, float* sims,
+                int64_t sims_stride, hipStream_t st) {
+    int64_t strips = (p->n + 15) / 16;
+    int64_t resident = (int64_t)p->cus * 8;
+    int64_t n_waves = strips < resident ? strips : resident;
+    if (n_waves < 1) n_waves = 1;
+    bool prof = p->prof_on && p->prof_n < p->prof_max;
+    if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+    if (m <= 16)
+        launch_scan_t<1, 8>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
+    else if (m <= 32)
+        launch_scan_t<2, 4>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
+    else
+        launch_scan_t<4, 2>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
+    CSLAM_HIP_TRY(hipGetLastError());
+    if (prof) {
+        CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
+        p->prof_n++;
+    }
+    return CSLAM_OK;
+}
+
+// sims for queries [0,m) (device, arbitrary stride) into p->sims-like buffer
+int compute_sims(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* sims,
+                 int64_t sims_stride, hipStream_t st) {
+    for (int q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
+        int mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
+        int mq_pad = mb <= 16 ? 16 : (mb <= 32 ? 32 : 64);
+        // double-buffer the staging area by pass parity so pass i+1's staging does not
+        // overwrite what pass i's scan is still reading is guaranteed by stream order already.
+        CSLAM_TRY(p->qstage.reserve((size_t)kMaxQueriesPerPass * p->dp * sizeof(float)));
+        CSLAM_TRY(p->rnq.reserve((size_t)kMaxQueriesPerPass * sizeof(float)));
+        hipLaunchKernelGGL(k_stage_queries, dim3((mq_pad + 3) / 4), dim3(256), 0, st,
+                           q_dev + (int64_t)q0 * q_stride, q_stride, p->dim, mb, mq_pad, p->dp,
+                           p->qstage.as<float>(), p->rnq.as<float>());
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), p->rnq.as<float>(), mb,
+                              sims + (int64_t)q0 * sims_stride, sims_stride, st));
+    }
+    return CSLAM_OK;
+}
+
+int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
+                   int32_t* out_idx, float* out_sim, hipStream_t st) {
+    int64_t n_in = p->n;
+    int64_t parts = (n_in + kSelectPart - 1) / kSelectPart;
+    if (parts <= 1) {
+        hipLaunchKernelGGL((k_select<true, true>), dim3(1, m), dim3(256), 0, st, sims,
+                           sims_stride, nullptr, (int64_t)0, n_in, k, nullptr, (int64_t)0,
+                           out_idx, out_sim);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+    // level 1: sims → candidates
+    int64_t cstride = parts * k;
+    CSLAM_TRY(p->cand_a.reserve((size_t)m * cstride * sizeof(uint64_t)));
+    hipLaunchKernelGGL((k_select<true, false>), dim3((unsigned)parts, m), dim3(256), 0, st, sims,
+                       sims_stride, nullptr, (int64_t)0, n_in, k, p->cand_a.as<uint64_t>(),
+                       cstride, nullptr, nullptr);
+    CSLAM_HIP_TRY(hipGetLastError());
+    DevBuf* src = &p->cand_a;
+    DevBuf* dst = &p->cand_b;
+    n_in = cstride;
+    int64_t in_stride = cstride;
+    while (true) {
+        parts = (n_in + kSelectPart - 1) / kSelectPart;
+        if (parts <= 1) {
+            hipLaunchKernelGGL((k_select<false, true>), dim3(1, m), dim3(256), 0, st, nullptr,
+                               (int64_t)0, src->as<uint64_t>(), in_stride, n_in, k, nullptr,
+                               (int64_t)0, out_idx, out_sim);
+            CSLAM_HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
+        int64_t ostride = parts * k;
+        CSLAM_TRY(dst->reserve((size_t)m * ostride * sizeof(uint64_t)));
+        hipLaunchKernelGGL((k_select<false, false>), dim3((unsigned)parts, m), dim3(256), 0, st,
+                           nullptr, (int64_t)0, src->as<uint64_t>(), in_stride, n_in, k,
+                           dst->as<uint64_t>(), ostride, nullptr, nullptr);
+        CSLAM_HIP_TRY(hipGetLastError());
+        DevBuf* t = src;
+        src = dst;
+        dst = t;
+        n_in = ostride;
+        in_stride = ostride;
+    }
+}
+
+int select_any_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
+                 int32_t* out_idx, float* out_sim, hipStream_t st) {
+    int64_t npow2 = 1;
+    while (npow2 < p->n) npow2 <<= 1;
+    if (npow2 < 2) npow2 = 2;
+    CSLAM_TRY(p->comp.reserve((size_t)m * npow2 * sizeof(uint64_t)));
+    uint64_t* comp = p->comp.as<uint64_t>();
+    hipLaunchKernelGGL(k_make_comp, dim3((unsigned)((npow2 + 255) / 256), m), dim3(256), 0, st,
+                       sims, sims_stride, p->n, npow2, comp);
+    for (int64_t size = 2; size <= npow2; size <<= 1)
+        for (int64_t stride = size >> 1; stride > 0; stride >>= 1)
+            hipLaunchKernelGGL(k_bitonic_step, dim3((unsigned)((npow2 / 2 + 255) / 256), m),
+                               dim3(256), 0, st, comp, npow2, size, stride);
+    hipLaunchKernelGGL(k_emit_sorted, dim3((unsigned)((k + 255) / 256), m), dim3(256), 0, st, comp,
+                       npow2, k, out_idx, out_sim);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k,
+                    int32_t* out_idx, float* out_sim, hipStream_t st) {
+    if (m <= 0 || k <= 0) return CSLAM_OK;
+    if (p->n == 0) {
+        int64_t total = (int64_t)m * k;
+        hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           total, out_idx, out_sim);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+    int64_t sims_stride = (p->n + 63) / 64 * 64;
+    int64_t chunk = m < kQueryChunk ? m : kQueryChunk;
+    CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
+    float* sims = p->sims.as<float>();
+    for (int q0 = 0; q0 < m; q0 += (int)kQueryChunk) {
+        int mb = m - q0 < (int)kQueryChunk ? m - q0 : (int)kQueryChunk;
+        CSLAM_TRY(compute_sims(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,
+                               st));
+        if (k <= kSelectMaxK)
+            CSLAM_TRY(select_small_k(p, sims, sims_stride, mb, k, out_idx + (int64_t)q0 * k,
+                                     out_sim + (int64_t)q0 * k, st));
+        else
+            CSLAM_TRY(select_any_k(p, sims, sims_stride, mb, k, out_idx + (int64_t)q0 * k,
+                                   out_sim + (int64_t)q0 * k, st));
+    }
+    return CSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_t** out) {
+    if (!out || dim <= 0 || capacity_hint < 0) return fail(CSLAM_E_INVALID, "pool_create: bad args");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CSLAM_E_NODEVICE, "pool_create: no HIP device visible");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(CSLAM_E_INVALID, "pool_create: device %d out of range (%d)", device_id, ndev);
+    CSLAM_HIP_TRY(hipSetDevice(device_id));
+    cslam_pool* p = new cslam_pool();
+    p->dim = dim;
+    p->dp = (int)pad16(dim);
+    p->device = device_id;
+    int rc = device_cu_count(device_id, &p->cus);
+    if (rc != CSLAM_OK) {
+        delete p;
+        return rc;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(CSLAM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    rc = pool_grow(p, capacity_hint > 0 ? capacity_hint : 1000, p->stream);
+    if (rc != CSLAM_OK) {
+        cslam_pool_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return CSLAM_OK;
+}
+
+int cslam_pool_destroy(cslam_pool_t* p) {
+    if (!p) return CSLAM_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    if (p->rows) (void)hipFree(p->rows);
+    if (p->inv_norm) (void)hipFree(p->inv_norm);
+    p->qstage.release();
+    p->rnq.release();
+    p->sims.release();
+    p->cand_a.release();
+    p->cand_b.release();
+    p->comp.release();
+    p->h_q.release();
+    p->h_idx.release();
+    p->h_sim.release();
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return CSLAM_OK;
+}
+
+int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
+    if (!p || (!rows && n_rows > 0) || n_rows < 0) return fail(CSLAM_E_INVALID, "pool_add: bad args");
+    if (n_rows == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_TRY(pool_grow(p, p->n + n_rows, p->stream));
+    CSLAM_HIP_TRY(hipMemcpy2DAsync(p->rows + p->n * p->dp, (size_t)p->dp * sizeof(float), rows,
+                                   (size_t)p->dim * sizeof(float), (size_t)p->dim * sizeof(float),
+                                   (size_t)n_rows, hipMemcpyHostToDevice, p->stream));
+    CSLAM_TRY(launch_norms(p, p->n, n_rows, p->stream));
+    CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    p->n += n_rows;
+    return CSLAM_OK;
+}
+
+int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64_t row_stride,
+                       void* stream) {
+    if (!p || (!rows_dev && n_rows > 0) || n_rows < 0 || row_stride < (p ? p->dim : 0))
+        return fail(CSLAM_E_INVALID, "pool_add_dev: bad args");
+    if (n_rows == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
+    hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
+                       row_stride, p->dim, p->rows + p->n * p->dp, (int64_t)p->dp, p->dp, n_rows);
+    CSLAM_HIP_TRY(hipGetLastError());
+    CSLAM_TRY(launch_norms(p, p->n, n_rows, st));
+    p->n += n_rows;
+    return CSLAM_OK;
+}
+
+int64_t cslam_pool_size(const cslam_pool_t* p) { return p ? p->n : 0; }
+int64_t cslam_pool_capacity(const cslam_pool_t* p) { return p ? p->cap : 0; }
+int cslam_pool_dim(const cslam_pool_t* p) { return p ? p->dim : 0; }
+
+int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float* out) {
+    if (!p || first < 0 || n < 0 || first + n > p->cap || (!out && n > 0))
+        return fail(CSLAM_E_INVALID, "pool_read_rows: range [%lld,+%lld) outside capacity %lld",
+                    (long long)first, (long long)n, (long long)(p ? p->cap : 0));
+    if (n == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    CSLAM_HIP_TRY(hipMemcpy2D(out, (size_t)p->dim * sizeof(float), p->rows + first * p->dp,
+                              (size_t)p->dp * sizeof(float), (size_t)p->dim * sizeof(float),
+                              (size_t)n, hipMemcpyDeviceToHost));
+    return CSLAM_OK;
+}
+
+int cslam_pool_read_inv_norms(const cslam_pool_t* p, int64_t first, int64_t n, float* out) {
+    if (!p || first < 0 || n < 0 || first + n > p->cap || (!out && n > 0))
+        return fail(CSLAM_E_INVALID, "pool_read_inv_norms: bad range");
+    if (n == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    CSLAM_HIP_TRY(hipMemcpy(out, p->inv_norm + first, (size_t)n * sizeof(float),
+                            hipMemcpyDeviceToHost));
+    return CSLAM_OK;
+}
+
+int cslam_pool_device_view(const cslam_pool_t* p, const float** rows_dev, int64_t* row_stride) {
+    if (!p || !rows_dev || !row_stride) return fail(CSLAM_E_INVALID, "pool_device_view: bad args");
+    *rows_dev = p->rows;
+    *row_stride = p->dp;
+    return CSLAM_OK;
+}
+
+int cslam_pool_search_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
+                          int n_queries, int k, int32_t* out_idx_dev, float* out_sim_dev,
+                          void* stream) {
+    if (!p || n_queries < 0 || k < 0 || (n_queries > 0 && (!queries_dev || query_stride < p->dim)) ||
+        ((int64_t)n_queries * k > 0 && (!out_idx_dev || !out_sim_dev)))
+        return fail(CSLAM_E_INVALID, "pool_search_dev: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev,
+                           st);
+}
+
+int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
+                                int n_queries, float* sims_dev, int64_t sims_stride,
+                                void* stream) {
+    if (!p || n_queries < 0 || (n_queries > 0 && (!queries_dev || query_stride < p->dim || !sims_dev)) ||
+        sims_stride < p->n)
+        return fail(CSLAM_E_INVALID, "pool_similarities_dev: bad args");
+    if (n_queries == 0 || p->n == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    return compute_sims(p, queries_dev, query_stride, n_queries, sims_dev, sims_stride, st);
+}
+
+int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int k,
+                      int32_t* out_idx, float* out_sim, int32_t* out_count) {
+    if (!p || n_queries < 0 || k < 0 || (n_queries > 0 && !queries) ||
+        ((int64_t)n_queries * k > 0 && (!out_idx || !out_sim)))
+        return fail(CSLAM_E_INVALID, "pool_search: bad args");
+    if (out_count)
+        for (int q = 0; q < n_queries; ++q) out_count[q] = (int32_t)(k < p->n ? k : p->n);
+    if (n_queries == 0 || k == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    size_t qbytes = (size_t)n_queries * p->dim * sizeof(float);
+    size_t obytes = (size_t)n_queries * k;
+    CSLAM_TRY(p->h_q.reserve(qbytes));
+    CSLAM_TRY(p->h_idx.reserve(obytes * sizeof(int32_t)));
+    CSLAM_TRY(p->h_sim.reserve(obytes * sizeof(float)));
+    CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, queries, qbytes, hipMemcpyHostToDevice, p->stream));
+    CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, p->h_idx.as<int32_t>(),
+                              p->h_sim.as<float>(), p->stream));
+    CSLAM_HIP_TRY(hipMemcpyAsync(out_idx, p->h_idx.p, obytes * sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, p->stream));
+    CSLAM_HIP_TRY(hipMemcpyAsync(out_sim, p->h_sim.p, obytes * sizeof(float), hipMemcpyDeviceToHost,
+                                 p->stream));
+    CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    return CSLAM_OK;
+}
+
+int cslam_pool_profile_begin(cslam_pool_t* p, int max_launches) {
+    if (!p || max_launches <= 0) return fail(CSLAM_E_INVALID, "profile_begin: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    while ((int)p->ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        CSLAM_HIP_TRY(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    p->prof_max = max_launches;
+    p->prof_n = 0;
+    p->prof_on = true;
+    return CSLAM_OK;
+}
+
+int cslam_pool_profile_end(cslam_pool_t* p, double* avg_scan_ms, int* n_launches) {
+    if (!p || !avg_scan_ms || !n_launches) return fail(CSLAM_E_INVALID, "profile_end: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    p->prof_on = false;
+    double total = 0.0;
+    for (int i = 0; i < p->prof_n; ++i) {
+        CSLAM_HIP_TRY(hipEventSynchronize(p->ev[2 * i + 1]));
+        float ms = 0.f;
+        CSLAM_HIP_TRY(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        total += ms;
+    }
+    *n_launches = p->prof_n;
+    *avg_scan_ms = p->prof_n > 0 ? total / p->prof_n : 0.0;
+    return CSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+"""MI355X-native NearestNeighborsMatching — host mirror of cslam/nns_matching.py:5-78.
+
+Same class name, method names, argument meaning and return types as the reference; all
+arithmetic runs in libcslam_hip.so (HIP, gfx950) through the C ABI of include/cslam_hip.h.
+No torch on this path and no CPU fallback: constructing a matcher without the built library or
+without a GPU raises.
+
+Differences that are deliberate:
+  * ties are broken by lowest row first (the reference's torch.argsort is unstable);
+  * `search_batch` / `search_best_batch` are additions that evaluate a whole message of
+    descriptors in one launch (the loop at
+    cslam/global_descriptor_loop_closure_detection.py:396-404).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _to_numpy_f32(vector):
+    """Accept np.ndarray (any float dtype), python lists or torch tensors
+    (nns_matching.py:30-31, :58-59)."""
+    if hasattr(vector, "detach") and hasattr(vector, "cpu"):  # torch tensor, without importing torch
+        vector = vector.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(vector), dtype=np.float32)
+
+
+class _DataView(object):
+    """What callers and tests do with `matcher.data` (nns_matching.py:19-21):
+    `len(data)`, `data[row, col]`, `data[row]`, `data.cpu().numpy()[:n]`, `data.shape`."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def _host(self):
+        o = self._owner
+        cap = o._capacity()
+        out = np.zeros((cap, o.dim), dtype=np.float32)
+        if cap > 0:
+            _lib.check(o._lib.cslam_pool_read_rows(o._pool, 0, cap, _lib.ptr(out)))
+        return out
+
+    def __len__(self):
+        return int(self._owner._capacity())
+
+    @property
+    def shape(self):
+        return (int(self._owner._capacity()), int(self._owner.dim))
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self._host()
+
+    def __getitem__(self, key):
+        o = self._owner
+        if isinstance(key, (int, np.integer)) or (
+                isinstance(key, tuple) and len(key) == 2
+                and isinstance(key[0], (int, np.integer))):
+            row = int(key if not isinstance(key, tuple) else key[0])
+            if row < 0:
+                row += len(self)
+            out = np.zeros((1, o.dim), dtype=np.float32)
+            _lib.check(o._lib.cslam_pool_read_rows(o._pool, row, 1, _lib.ptr(out)))
+            return out[0] if not isinstance(key, tuple) else out[0][key[1]]
+        return self._host()[key]
+
+    def __array__(self, dtype=None, copy=None):
+        h = self._host()
+        return h if dtype is None else h.astype(dtype)
+
+
+class NearestNeighborsMatching(object):
+    """Nearest Neighbor matching of description vectors (device-resident pool)."""
+
+    def __init__(self, dim=None, device_id=0, capacity_hint=0):
+        """
+        Args:
+            dim (int, optional): Global descriptor size. Defaults to None (fixed by the first
+                add_item, nns_matching.py:34-36).
+            device_id (int): HIP device of the pool.
+            capacity_hint (int): rows to reserve (0 → 1000 like the reference).
+        """
+        self._lib = _lib.load()
+        if self._lib.cslam_device_count() <= 0:
+            raise _lib.CslamHipError(_lib.CSLAM_E_NODEVICE,
+                                     "no HIP device visible; cslam_amd has no CPU path")
+        self.n = 0
+        self.device_id = int(device_id)
+        self.device = f"hip:{self.device_id}"
+        self.dim = dim
+        self.items = dict()
+        self._pool = None
+        self._capacity_hint = int(capacity_hint)
+        self.data = []  # like the reference until the dimension is known
+        if dim is not None:
+            self._create(int(dim))
+
+    # -- lifetime ------------------------------------------------------------------------
+    def _create(self, dim):
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.cslam_pool_create(dim, self._capacity_hint, self.device_id,
+                                               ctypes.byref(handle)))
+        self._pool = handle
+        self.dim = dim
+        self.data = _DataView(self)
+
+    def _capacity(self):
+        return self._lib.cslam_pool_capacity(self._pool) if self._pool else 0
+
+    def close(self):
+        if getattr(self, "_pool", None):
+            self._lib.cslam_pool_destroy(self._pool)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        """cslam_pool_t* for zero-copy callers (bench.py, multi_robot.py)."""
+        return self._pool
+
+    # -- add_item (nns_matching.py:23-42) ------------------------------------------------
+    def add_item(self, vector, item):
+        """Add item to the matching list
+
+        Args:
+            vector (np.array): descriptor
+            item: identification info (e.g., int)
+        """
+        vector = _to_numpy_f32(vector).reshape(-1)
+        if self._pool is None:
+            self._create(len(vector))
+        row = vector.reshape(1, self.dim)
+        _lib.check(self._lib.cslam_pool_add(self._pool, _lib.ptr(row), 1))
+        self.items[self.n] = item
+        self.n += 1
+
+    def add_items(self, vectors, items):
+        """Batched add_item: vectors [B, dim], items: sequence of B ids."""
+        vectors = _to_numpy_f32(vectors)
+        if vectors.ndim != 2:
+            raise ValueError("add_items expects a [B, dim] array")
+        if len(items) != vectors.shape[0]:
+            raise ValueError("add_items: len(items) != number of rows")
+        if vectors.shape[0] == 0:
+            return
+        if self._pool is None:
+            self._create(vectors.shape[1])
+        if vectors.shape[1] != self.dim:
+            raise ValueError(f"descriptor size {vectors.shape[1]} != pool dim {self.dim}")
+        _lib.check(self._lib.cslam_pool_add(self._pool, _lib.ptr(vectors), vectors.shape[0]))
+        for it in items:
+            self.items[self.n] = it
+            self.n += 1
+
+    def add_items_device(self, dev_ptr, n_rows, row_stride, items, stream=None):
+        """Append rows that already live in HBM (e.g. an all-gathered block)."""
+        if self._pool is None:
+            raise ValueError("pool dimension unknown; construct with dim=")
+        _lib.check(self._lib.cslam_pool_add_dev(self._pool, ctypes.c_void_p(dev_ptr), n_rows,
+                                                row_stride, ctypes.c_void_p(stream or 0)))
+        for it in items:
+            self.items[self.n] = it
+            self.n += 1
+
+    # -- search (nns_matching.py:44-63) --------------------------------------------------
+    def search_batch(self, queries, k):
+        """Top-k of every query row in one pass.
+
+        Returns (rows[M, kk] int32, sims[M, kk] float32) with kk = min(k, n)."""
+        queries = _to_numpy_f32(queries)
+        if queries.ndim == 1:
+            queries = queries.reshape(1, -1)
+        m = queries.shape[0]
+        if self._pool is None or self.n == 0 or k <= 0 or m == 0:
+            return np.zeros((m, 0), np.int32), np.zeros((m, 0), np.float32)
+        if queries.shape[1] != self.dim:
+            raise ValueError(f"query size {queries.shape[1]} != pool dim {self.dim}")
+        k = int(k)
+        idx = np.empty((m, k), np.int32)
+        sim = np.empty((m, k), np.float32)
+        cnt = np.empty(m, np.int32)
+        _lib.check(self._lib.cslam_pool_search(self._pool, _lib.ptr(queries), m, k,
+                                               _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt)))
+        kk = int(cnt[0])
+        return idx[:, :kk], sim[:, :kk]
+
+    def search(self, query, k):
+        """Search for nearest neighbors
+
+        Args:
+            query (np.array): descriptor to match
+            k (int): number of best matches to return
+
+        Returns:
+            list(int, np.array): best matches
+        """
+        if len(self.data) == 0:
+            return [], []
+        rows, sims = self.search_batch(_to_numpy_f32(query).reshape(1, -1), k)
+        return [self.items[int(r)] for r in rows[0]], sims[0]
+
+    def search_best(self, query):
+        """Search for the nearest neighbor
+
+        Args:
+            query (np.array): descriptor to match
+
+        Returns:
+            int, np.array: best match
+        """
+        if len(self.data) == 0:
+            return None, None
+        items, similarities = self.search(query, 1)
+        return items[0], similarities[0]
+
+    def search_best_batch(self, queries):
+        """search_best for every row of `queries`: (items list, sims[M]); empty pool →
+        ([None]*M, [None]*M)."""
+        queries = _to_numpy_f32(queries)
+        if queries.ndim == 1:
+            queries = queries.reshape(1, -1)
+        if len(self.data) == 0 or self.n == 0:
+            return [None] * queries.shape[0], [None] * queries.shape[0]
+        rows, sims = self.search_batch(queries, 1)
+        return [self.items[int(r)] for r in rows[:, 0]], sims[:, 0]

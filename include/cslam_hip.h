@@ -1,0 +1,144 @@
+/*
+ * cslam_hip.h — C ABI of libcslam_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the inter-robot loop-closure hot path of nhahn/cslam:
+ *   - descriptor pool + brute-force cosine kNN   (replaces cslam/nns_matching.py:5-78)
+ *   - MAC candidate selection numerics           (replaces cslam/mac/mac.py:19-233,
+ *                                                 cslam/mac/utils.py:44-122 and the networkx
+ *                                                 `tracemin_lu` Fiedler solve called at mac.py:52-58)
+ *
+ * The reference has no FFI for this path (plain Python classes); the entry
+ * points below are what a ctypes binding inside those classes would call.  INTEGRATION.md
+ * shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (CSLAM_E_*); the message of the last
+ *     error on the calling thread is returned by cslam_last_error().
+ *   - `*_dev` arguments are device (HBM) pointers, everything else is host memory owned by
+ *     the caller.  `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - one caller thread per handle (the reference node is a single-threaded rclpy executor).
+ *   - no torch types, no C++ types.
+ */
+#ifndef CSLAM_HIP_H
+#define CSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSLAM_OK 0
+#define CSLAM_E_INVALID (-1)      /* bad argument */
+#define CSLAM_E_HIP (-2)          /* HIP runtime error (message has the hipError string) */
+#define CSLAM_E_NODEVICE (-3)     /* no gfx950 device visible */
+#define CSLAM_E_DISCONNECTED (-4) /* Laplacian of a disconnected graph: the reference's SuperLU
+                                     raises "Factor is exactly singular" here (acm.py:455 catches it) */
+#define CSLAM_E_NOCONV (-5)       /* eigen-solver did not reach the tolerance */
+
+const char* cslam_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int cslam_abi_version(void);
+/* Number of visible HIP devices (does not create a context). */
+int cslam_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor pool  — NearestNeighborsMatching state (nns_matching.py:9-21)
+ * Rows are stored un-normalised, fp32, row-major with the row stride padded to a multiple of
+ * 16 floats; 1/max(||x||,1e-8) is cached per row at add time.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cslam_pool cslam_pool_t;
+
+/* dim > 0; capacity_hint rows are reserved up front (0 = 1000 like nns_matching.py:21). */
+int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_t** out);
+int cslam_pool_destroy(cslam_pool_t* pool);
+
+/* add_item (nns_matching.py:23-42), batched: append n_rows dense rows [n_rows][dim]. */
+int cslam_pool_add(cslam_pool_t* pool, const float* rows, int64_t n_rows);
+/* same, rows already in HBM; row_stride in floats (>= dim). Async on `stream`. */
+int cslam_pool_add_dev(cslam_pool_t* pool, const float* rows_dev, int64_t n_rows,
+                       int64_t row_stride, void* stream);
+
+int64_t cslam_pool_size(const cslam_pool_t* pool);     /* self.n */
+int64_t cslam_pool_capacity(const cslam_pool_t* pool); /* len(self.data) */
+int cslam_pool_dim(const cslam_pool_t* pool);
+/* `.data[first:first+n]` → host [n][dim] (tests/test_sparse_matching.py:36,49,66). */
+int cslam_pool_read_rows(const cslam_pool_t* pool, int64_t first, int64_t n, float* out);
+/* cached 1/max(||row||,1e-8) for rows [first, first+n) → host. */
+int cslam_pool_read_inv_norms(const cslam_pool_t* pool, int64_t first, int64_t n, float* out);
+/* device address of the row storage and its stride in floats (for zero-copy consumers). */
+int cslam_pool_device_view(const cslam_pool_t* pool, const float** rows_dev, int64_t* row_stride);
+
+/* search (nns_matching.py:44-63) for n_queries queries at once.
+ *   queries  [n_queries][dim] fp32 (host)
+ *   out_idx  [n_queries][k] int32 row numbers, best first; ties → lowest row first
+ *   out_sim  [n_queries][k] fp32 cosine similarities
+ *   out_count[n_queries]    number of valid results = min(k, size)
+ * Entries past out_count are -1 / -inf.  Empty pool → all counts 0 (nns_matching.py:54-55). */
+int cslam_pool_search(cslam_pool_t* pool, const float* queries, int n_queries, int k,
+                      int32_t* out_idx, float* out_sim, int32_t* out_count);
+/* same with queries and outputs resident in HBM; asynchronous on `stream`.
+ * query_stride in floats (>= dim). out_count may be NULL. */
+int cslam_pool_search_dev(cslam_pool_t* pool, const float* queries_dev, int64_t query_stride,
+                          int n_queries, int k, int32_t* out_idx_dev, float* out_sim_dev,
+                          void* stream);
+/* Similarities only: sims_dev[q * sims_stride + row] for row < size (all rows, unsorted). */
+int cslam_pool_similarities_dev(cslam_pool_t* pool, const float* queries_dev,
+                                int64_t query_stride, int n_queries, float* sims_dev,
+                                int64_t sims_stride, void* stream);
+
+/* Introspection used by bench.py to time the dominant kernel with HIP events on the launch
+ * stream: average duration in ms of the last `n` scan-kernel launches recorded since
+ * cslam_pool_profile_begin().  */
+int cslam_pool_profile_begin(cslam_pool_t* pool, int max_launches);
+int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launches);
+
+/* ------------------------------------------------------------------------------------------
+ * MAC problem  — cslam/mac/mac.py:19-233
+ * Nodes 0..n-1; fixed edges (i,j,weight) form L_odom (mac.py:22); candidates (i,j,weight) are
+ * weighted by w in [0,1]^m (mac.py:61-77).  All arithmetic fp64.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cslam_mac cslam_mac_t;
+
+/* MAC.__init__ (mac.py:21-33) + weight_graph_lap_from_edge_list (utils.py:44-81). */
+int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* fixed_j,
+                     const double* fixed_w, int64_t n_fixed, const int32_t* cand_i,
+                     const int32_t* cand_j, const double* cand_w, int64_t n_cand, int device_id,
+                     cslam_mac_t** out);
+int cslam_mac_destroy(cslam_mac_t* mac);
+
+/* combined_laplacian(w, tol=1e-10) (mac.py:61-77) as CSR with duplicates summed
+ * (utils.py:121-122).  Two-call protocol: indptr/indices/data may be NULL to query *nnz. */
+int cslam_mac_laplacian(cslam_mac_t* mac, const double* w, double tol, int64_t* nnz,
+                        int32_t* indptr, int32_t* indices, double* data);
+
+/* evaluate_fiedler_pair(w) (mac.py:79-96 → networkx tracemin_lu, tol 1e-8).
+ *   lambda2: Fiedler value; v[n]: unit Fiedler vector, sign fixed so that the first entry
+ *   of largest magnitude is positive; iters: solver iterations used.
+ * Returns CSLAM_E_DISCONNECTED if L(w) is the Laplacian of a disconnected graph. */
+int cslam_mac_fiedler(cslam_mac_t* mac, const double* w, double tol, double* lambda2,
+                      double* v, int32_t* iters);
+
+/* grad_from_fiedler (mac.py:112-130): g[k] = weight_k (v_i - v_j)^2. */
+int cslam_mac_grad(cslam_mac_t* mac, const double* v, double* g);
+
+/* round_solution (mac.py:132-147): 0/1 mask of the k largest x; ties → lowest index kept. */
+int cslam_topk_mask(const double* x, int64_t m, int64_t k, double* mask);
+/* round_solution_tiebreaker (mac.py:168-189): k largest by (round(w,decimals), weight). */
+int cslam_mac_round_tiebreak(cslam_mac_t* mac, const double* w, int64_t k, int decimals,
+                             double* mask);
+
+/* fw_subset (mac.py:191-233): whole Frank-Wolfe loop on the device.
+ *   w_init[m] in, w_round[m] (0/1), w_relaxed[m], *upper out; *iters_done = FW iterations run;
+ *   lambda_trace (may be NULL) receives f_i of every iteration (max_iters entries). */
+int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int max_iters,
+                        double duality_gap_tol, double* w_round, double* w_relaxed,
+                        double* upper, int32_t* iters_done, double* lambda_trace);
+
+/* Solver statistics of the last cslam_mac_fiedler / cslam_mac_fw_subset call. */
+int cslam_mac_stats(const cslam_mac_t* mac, int64_t* spmv_count, double* device_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSLAM_HIP_H */

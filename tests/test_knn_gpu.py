@@ -1,0 +1,155 @@
+"""Parity of the HIP kNN path (through the C ABI) with the CPU oracle — bit exact.
+
+Mirrors the reference's tests/test_sparse_matching.py:51-81 (test_similarity) and adds the
+edge cases of cslam/nns_matching.py (empty pool, growth, k > n, ragged dims, ties, zero rows).
+"""
+import numpy as np
+import pytest
+
+from oracle import knn as oracle_knn
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(gpu, X, **kw):
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    m = NearestNeighborsMatching(**kw)
+    m.add_items(X, list(range(X.shape[0])))
+    return m
+
+
+def _check(gpu, X, Q, k):
+    m = _pool(gpu, X)
+    rows, sims = m.search_batch(Q, k)
+    o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+    kk = int(o_cnt[0])
+    assert rows.shape == (Q.shape[0], kk)
+    np.testing.assert_array_equal(rows, o_idx[:, :kk])
+    assert sims.tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    m.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (100, 100, 100, 100),     # the reference's test_similarity shape (k == n → bitonic path)
+    (1000, 128, 7, 10),       # cfg1
+    (1, 10, 1, 1),
+    (17, 10, 3, 5),
+    (4097, 64, 16, 10),       # two select parts
+    (5000, 4096, 16, 10),     # cfg2 row shape
+    (3000, 4096, 33, 1),      # T=4 scan
+    (3000, 256, 20, 3),       # T=2 scan
+    (9000, 48, 300, 64),      # query chunking (> 256 queries), k = 64
+    (600, 33, 2, 200),        # bitonic path, ragged dim
+])
+def test_search_matches_oracle(gpu, n, d, m, k):
+    rs = np.random.RandomState(n * 31 + d)
+    X = rs.rand(n, d).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = rs.rand(m, d).astype(np.float32)
+    _check(gpu, X, Q, k)
+
+
+def test_negative_and_unnormalised(gpu):
+    rs = np.random.RandomState(5)
+    X = (rs.randn(2500, 200) * 3).astype(np.float32)
+    Q = rs.randn(9, 200).astype(np.float32)
+    _check(gpu, X, Q, 10)
+
+
+def test_ties_duplicates_and_zero_rows(gpu):
+    rs = np.random.RandomState(11)
+    X = rs.rand(500, 32).astype(np.float32)
+    X[100] = X[7]          # exact duplicates → tie broken by lowest row
+    X[300] = X[7]
+    X[50] = 0.0            # zero row → similarity 0 (clamped norm, nns_matching.py:61 eps)
+    Q = np.vstack([X[7], rs.rand(32).astype(np.float32), np.zeros(32, np.float32)])
+    m = _pool(gpu, X)
+    rows, sims = m.search_batch(Q, 5)
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 5)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    assert list(rows[0][:3]) == [7, 100, 300]
+    assert np.all(sims[2] == 0.0) and list(rows[2]) == [0, 1, 2, 3, 4]
+    m.close()
+
+
+def test_inverse_norms_match_oracle(gpu):
+    rs = np.random.RandomState(3)
+    X = rs.rand(300, 1000).astype(np.float32) * 7
+    m = _pool(gpu, X)
+    got = np.empty(300, np.float32)
+    from cslam_amd import _lib
+    _lib.check(gpu.cslam_pool_read_inv_norms(m.handle, 0, 300, _lib.ptr(got)))
+    assert got.tobytes() == oracle_knn.inv_norms(X).tobytes()
+    m.close()
+
+
+def test_similarity_ordering_like_reference(gpu):
+    """tests/test_sparse_matching.py:51-81: cosine order == euclidean order on unit vectors."""
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    rs = np.random.RandomState(0)
+    nnsm = NearestNeighborsMatching()
+    for i in range(100):
+        d = rs.rand(100)
+        nnsm.add_item(d / np.linalg.norm(d), i)
+    k = 100
+    for _ in range(100):
+        query = rs.rand(100)
+        query = query / np.linalg.norm(query)
+        ds = np.linalg.norm(query[np.newaxis, :] - nnsm.data.cpu().numpy()[:nnsm.n], axis=1)
+        ns_dist = np.argsort(ds)[:k]
+        ns_sim, sims = nnsm.search(query, k)
+        assert np.all(sims[:-1] >= sims[1:])
+        for j in range(k):
+            id_d, id_s = ns_dist[j], ns_sim[j]
+            if id_d != id_s:
+                if abs(sims[id_d] - sims[id_s]) < 1e-6 or abs(ds[id_d] - ds[id_s]) < 1e-6:
+                    continue
+            assert ns_dist[j] == ns_sim[j]
+        best, _ = nnsm.search_best(query)
+        assert ns_dist[0] == best
+
+
+def test_growth_and_data_view(gpu):
+    """Pool growth 1000 → 2000 → 4000 (nns_matching.py:33-38) keeps rows and results."""
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    rs = np.random.RandomState(2)
+    X = rs.rand(2500, 24).astype(np.float32)
+    m = NearestNeighborsMatching()
+    assert m.search(X[0], 3) == ([], []) and m.search_best(X[0]) == (None, None)
+    for i in range(1200):
+        m.add_item(X[i].astype(np.float64), 10 * i)   # float64 input is cast (nns_matching.py:31)
+    assert len(m.data) == 2000 and m.n == 1200
+    m.add_items(X[1200:], [10 * i for i in range(1200, 2500)])
+    assert len(m.data) == 4000 and m.n == 2500
+    np.testing.assert_array_equal(m.data.cpu().numpy()[:2500], X)
+    assert m.data[1234, 5] == X[1234, 5]
+    np.testing.assert_array_equal(m.data[17], X[17])
+    items, sims = m.search(X[777], 4)
+    o_idx, o_sim, _ = oracle_knn.search(X, X[777:778], 4)
+    assert items == [10 * int(i) for i in o_idx[0]] and items[0] == 7770
+    assert sims.tobytes() == o_sim[0].tobytes()
+    m.close()
+
+
+def test_device_resident_queries(gpu):
+    """cslam_pool_search_dev with queries/outputs in HBM (the bench / multi-GPU entry)."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    from cslam_amd import _lib
+    rs = np.random.RandomState(9)
+    X = rs.rand(3000, 512).astype(np.float32)
+    Q = rs.rand(10, 512).astype(np.float32)
+    m = _pool(gpu, X)
+    q = torch.from_numpy(Q).cuda()
+    idx = torch.empty((10, 10), dtype=torch.int32, device="cuda")
+    sim = torch.empty((10, 10), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(gpu.cslam_pool_search_dev(m.handle, ctypes.c_void_p(q.data_ptr()), 512, 10, 10,
+                                         ctypes.c_void_p(idx.data_ptr()),
+                                         ctypes.c_void_p(sim.data_ptr()), ctypes.c_void_p(st)))
+    torch.cuda.synchronize()
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 10)
+    np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+    assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
+    m.close()
