@@ -74,6 +74,25 @@ SIGNATURES = {
 _LIB = None
 
 
+def _preload_shared_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, looked up as 'libamdhip64.so'), so if
+    /opt/rocm's copy were mapped first a later `torch.cuda` init would map a second runtime
+    and fail with 'No HIP GPUs are available'.  When torch is installed, map its copy first
+    (without importing torch); libcslam_hip.so's NEEDED libamdhip64.so.7 then resolves to it by
+    SONAME.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load libcslam_hip.so (once).  Raises if it has not been built."""
     global _LIB
@@ -83,6 +102,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. "
             "Run `make -C cslam_amd/csrc` (there is no CPU fallback).")
+    _preload_shared_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -16,6 +16,7 @@
 //                   (similarity desc, row asc) composites, wave-shuffle + LDS reduction
 //   k_bitonic_step  any k: full bitonic sort of the composites in HBM (rare path)
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -69,9 +70,11 @@ __device__ inline float wave_sumsq(const float* row, int dp, int lane) {
 }
 
 __device__ inline float inv_norm_from_sumsq(float ss) {
-    float nrm = __fsqrt_rn(ss);
+    // plain sqrtf and '/' are IEEE correctly rounded under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn/__fdiv_rn intrinsics are NOT).
+    float nrm = __builtin_sqrtf(ss);
     if (!(nrm > 1e-8f)) nrm = 1e-8f;
-    return __fdiv_rn(1.0f, nrm);
+    return 1.0f / nrm;
 }
 
 __global__ __launch_bounds__(256) void k_inv_norm(const float* __restrict__ rows, int64_t stride,
@@ -133,18 +136,28 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan: sims[q][row] for a block of 16*T staged queries against rows [0,n)
-//   grid: W waves (4 per block); wave w owns rows [w*n/W, (w+1)*n/W)
+// k_scan<T,S,U>: raw dot products dots[q][row] of 16*T staged queries against rows [0,n)
+//   grid: W waves (4 per block); wave w owns the byte-balanced row range [w*n/W, (w+1)*n/W)
+//   and walks it in groups of S 16-row strips (S*T independent MFMA accumulators).
 //   lane l: r = l & 15 (row in strip / query column), g = l >> 4 (k slot)
-//   A = X[row r][kb + 4g .. +3], B = Q[col r][kb + 4g .. +3]; MFMA j consumes component j
-//   → chain order inside a 16-block: k = kb + 4g + j, j outer, g inner
+//   A_s = X[row(s,r)][16kb + 4g .. +3], B_t = Q[col 16t + r][16kb + 4g .. +3]; MFMA j consumes
+//   component j → chain order inside a 16-block: k = 16kb + 4g + j, j outer, g inner
+//   (DESIGN.md §3); every output is ONE chain, whatever T/S/U.
+//   Both operands run through a U-deep register ring that is refilled right after use and
+//   keeps running ACROSS group boundaries, so a wave always has U*S KiB of X in flight.  The
+//   loop body is branch-free apart from the group epilogue (stores only), which lets the
+//   compiler emit counted s_waitcnt vmcnt(N) instead of draining the queue.
+//   Why S strips share one B fragment: all waves of the chip walk the (L2-resident) query
+//   block in near lockstep, which hot-spots one L2 channel per XCD; at S=1 the query stream
+//   (1 byte per X byte) capped the scan at ~3.8 TB/s.  S=4 cuts it to 1/4.
+//   The cosine scaling (x 1/||x|| x 1/||q||) is applied by the consumer (k_select/k_scale):
+//   a load in the epilogue would sit behind the ring's HBM loads (loads return in order).
+//   Requires nkb % U == 0 (the host picks U).
 // ---------------------------------------------------------------------------------------------
-template <int T, int U>
+template <int T, int S, int U>
 __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64_t xs, int64_t n,
-                                              int dp, const float* __restrict__ Q,
-                                              const float* __restrict__ rnx,
-                                              const float* __restrict__ rnq, int m_valid,
-                                              float* __restrict__ sims, int64_t sims_stride,
+                                              int dp, const float* __restrict__ Q, int m_valid,
+                                              float* __restrict__ dots, int64_t dots_stride,
                                               int64_t n_waves) {
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_waves) return;
@@ -153,81 +166,110 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
     const int g = lane >> 4;
     const int64_t lo = (w * n) / n_waves;
     const int64_t hi = ((w + 1) * n) / n_waves;
-    const int nkb = dp >> 4;            // 16-float k blocks
-    const int nchunk = nkb / U;         // full chunks of U k-blocks
-    const int ktail = nchunk * U;       // first k-block of the tail
+    const int ipk = (dp >> 4) / U;  // ring turns per group
+    const int64_t ngroups = (hi - lo + 16 * S - 1) / (16 * S);
+    const int64_t total = ngroups * ipk;
 
     const f32x4* qp[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
         qp[t] = reinterpret_cast<const f32x4*>(Q + (int64_t)(t * 16 + r) * dp + 4 * g);
 
-    for (int64_t r0 = lo; r0 < hi; r0 += 16) {
-        int64_t row = r0 + r;
-        if (row >= hi) row = hi - 1;  // clamp: duplicates hit L1, results are not stored
-        const f32x4* xp = reinterpret_cast<const f32x4*>(X + row * xs + 4 * g);
+    auto rowptr = [&](int64_t grp, int s) {
+        int64_t row = lo + grp * (16 * S) + 16 * s + r;
+        if (row >= hi) row = hi - 1;  // clamp: duplicates hit L1, their results are not stored
+        return reinterpret_cast<const f32x4*>(X + row * xs + 4 * g);
+    };
 
-        f32x4 acc[T];
+    f32x4 a[U][S];
+    f32x4 b[U][T];
+    f32x4 acc[S][T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        f32x4 a_cur[U], a_nxt[U];
-        if (nchunk > 0) {
+    auto store_group = [&](int64_t grp) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) a_cur[u] = xp[u * 4];
-        }
-        for (int c = 0; c < nchunk; ++c) {
-            const int kb0 = c * U;
-            if (c + 1 < nchunk) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) a_nxt[u] = xp[(kb0 + U + u) * 4];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                f32x4 b[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) b[t] = qp[t][(kb0 + u) * 4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int t = 0; t < T; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j], b[t][j],
-                                                                      acc[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) a_cur[u] = a_nxt[u];
-        }
-        for (int kb = ktail; kb < nkb; ++kb) {
-            f32x4 a = xp[kb * 4];
+        for (int s = 0; s < S; ++s) {
+            const int64_t r0 = lo + grp * (16 * S) + 16 * s + 4 * g;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                f32x4 b = qp[t][kb * 4];
+                const int q = t * 16 + r;
+                if (q < m_valid) {
+                    float* out = dots + (int64_t)q * dots_stride + r0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+                        if (r0 + e < hi) out[e] = acc[s][t][e];
+                }
+                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+    };
+    auto mfma_slot = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s][j], b[u][t][j],
+                                                                     acc[s][t], 0, 0, 0);
+    };
 
-        // epilogue: lane holds D[row = 4g + reg][col = r]
+    {
+        const f32x4* x0[S];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int q = t * 16 + r;
-            if (q < m_valid) {
-                const float sq = rnq[q];
-                float* out = sims + (int64_t)q * sims_stride;
+        for (int s = 0; s < S; ++s) x0[s] = rowptr(0, s);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int64_t orow = r0 + 4 * g + e;
-                    if (orow < hi) {
-                        float s = (acc[t][e] * rnx[orow]) * sq;
-                        if (s == 0.0f) s = 0.0f;
-                        out[orow] = s;
-                    }
-                }
-            }
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[u][s] = x0[s][u * 4];
+#pragma unroll
+            for (int t = 0; t < T; ++t) b[u][t] = qp[t][u * 4];
         }
     }
+    int64_t grp = 0;  // group of the ring's current contents
+    int turn = 0;     // ring turn inside the group
+    for (int64_t it = 0; it + 1 < total; ++it) {
+        int nturn = turn + 1;
+        int64_t ngrp = grp;
+        if (nturn == ipk) {
+            nturn = 0;
+            ngrp = grp + 1;
+        }
+        const f32x4* xn[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) xn[s] = rowptr(ngrp, s) + (int64_t)nturn * U * 4;
+        const int qn = nturn * U * 4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mfma_slot(u);
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[u][s] = xn[s][u * 4];
+#pragma unroll
+            for (int t = 0; t < T; ++t) b[u][t] = qp[t][qn + u * 4];
+        }
+        if (nturn == 0) store_group(grp);
+        grp = ngrp;
+        turn = nturn;
+    }
+    // last ring turn: nothing left to prefetch
+#pragma unroll
+    for (int u = 0; u < U; ++u) mfma_slot(u);
+    store_group(grp);
+}
+
+// cosine scaling of raw dots in place: sims[q][i] = (dot * rnx[i]) * rnq[q]
+__global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t stride, int64_t n,
+                                               const float* __restrict__ rnx,
+                                               const float* __restrict__ rnq) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t q = blockIdx.y;
+    if (i >= n) return;
+    float s = (sims[q * stride + i] * rnx[i]) * rnq[q];
+    if (s == 0.0f) s = 0.0f;
+    sims[q * stride + i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -236,6 +278,8 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
 template <bool FROM_SIMS, bool FINAL>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
                                                 int64_t sims_stride,
+                                                const float* __restrict__ rnx,
+                                                const float* __restrict__ rnq,
                                                 const uint64_t* __restrict__ cin,
                                                 int64_t cin_stride, int64_t n_in, int k,
                                                 uint64_t* __restrict__ cout, int64_t cout_stride,
@@ -255,7 +299,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
         uint64_t c = 0;
         if (i < n_in) {
             if (FROM_SIMS)
-                c = make_comp(sims[q * sims_stride + i], (uint32_t)i);
+                c = make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], (uint32_t)i);
             else
                 c = cin[q * cin_stride + i];
         }
@@ -304,12 +348,15 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
 // any-k path: bitonic sort of composites (descending) in HBM
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_make_comp(const float* __restrict__ sims,
-                                                   int64_t sims_stride, int64_t n, int64_t npow2,
-                                                   uint64_t* __restrict__ comp) {
+                                                   int64_t sims_stride,
+                                                   const float* __restrict__ rnx,
+                                                   const float* __restrict__ rnq, int64_t n,
+                                                   int64_t npow2, uint64_t* __restrict__ comp) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t q = blockIdx.y;
     if (i >= npow2) return;
-    comp[q * npow2 + i] = (i < n) ? make_comp(sims[q * sims_stride + i], (uint32_t)i) : 0ull;
+    comp[q * npow2 + i] =
+        (i < n) ? make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], (uint32_t)i) : 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_bitonic_step(uint64_t* __restrict__ comp, int64_t npow2,
@@ -360,6 +407,7 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
 struct cslam_pool {
     int dim = 0, dp = 0, device = 0, cus = 256;
     int64_t n = 0, cap = 0;
+    int64_t xs = 0;             // row stride in floats (dp + anti-camping pad)
     float* rows = nullptr;      // [cap][dp]
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
@@ -379,16 +427,16 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     while (ncap < want_rows) ncap *= 2;  // nns_matching.py:38 doubles
     float* nrows = nullptr;
     float* nnorm = nullptr;
-    CSLAM_HIP_TRY(hipMalloc(&nrows, (size_t)ncap * p->dp * sizeof(float)));
+    CSLAM_HIP_TRY(hipMalloc(&nrows, (size_t)ncap * p->xs * sizeof(float)));
     CSLAM_HIP_TRY(hipMalloc(&nnorm, (size_t)ncap * sizeof(float)));
     if (p->n > 0) {
-        CSLAM_HIP_TRY(hipMemcpyAsync(nrows, p->rows, (size_t)p->n * p->dp * sizeof(float),
+        CSLAM_HIP_TRY(hipMemcpyAsync(nrows, p->rows, (size_t)p->n * p->xs * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
         CSLAM_HIP_TRY(hipMemcpyAsync(nnorm, p->inv_norm, (size_t)p->n * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
     }
-    CSLAM_HIP_TRY(hipMemsetAsync(nrows + p->n * p->dp, 0,
-                                 (size_t)(ncap - p->n) * p->dp * sizeof(float), st));
+    CSLAM_HIP_TRY(hipMemsetAsync(nrows + p->n * p->xs, 0,
+                                 (size_t)(ncap - p->n) * p->xs * sizeof(float), st));
     CSLAM_HIP_TRY(hipMemsetAsync(nnorm + p->n, 0, (size_t)(ncap - p->n) * sizeof(float), st));
     CSLAM_HIP_TRY(hipStreamSynchronize(st));
     if (p->rows) CSLAM_HIP_TRY(hipFree(p->rows));
@@ -402,35 +450,59 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
 int launch_norms(cslam_pool* p, int64_t first, int64_t count, hipStream_t st) {
     if (count <= 0) return CSLAM_OK;
     unsigned blocks = (unsigned)((count + 3) / 4);
-    hipLaunchKernelGGL(k_inv_norm, dim3(blocks), dim3(256), 0, st, p->rows, (int64_t)p->dp, first,
+    hipLaunchKernelGGL(k_inv_norm, dim3(blocks), dim3(256), 0, st, p->rows, p->xs, first,
                        count, p->dp, p->inv_norm);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
 
-template <int T, int U>
-void launch_scan_t(cslam_pool* p, const float* Q, const float* rnq, int m_valid, float* sims,
-                   int64_t sims_stride, int64_t n_waves, hipStream_t st) {
+template <int T, int S, int U>
+void launch_scan_t(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
+                   int64_t n_waves, hipStream_t st) {
     unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL((k_scan<T, U>), dim3(blocks), dim3(256), 0, st, p->rows, (int64_t)p->dp,
-                       p->n, p->dp, Q, p->inv_norm, rnq, m_valid, sims, sims_stride, n_waves);
+    hipLaunchKernelGGL((k_scan<T, S, U>), dim3(blocks), dim3(256), 0, st, p->rows, p->xs, p->n,
+                       p->dp, Q, m_valid, dots, dots_stride, n_waves);
 }
 
-// similarities of `m` staged queries (m <= 64) → sims[q*stride + row]
-int launch_scan(cslam_pool* p, const float* Qstage, const float* rnq, int m, float* sims,
-                int64_t sims_stride, hipStream_t st) {
-    int64_t strips = (p->n + 15) / 16;
-    int64_t resident = (int64_t)p->cus * 8;
-    int64_t n_waves = strips < resident ? strips : resident;
+template <int T, int S, int UMAX>
+void launch_scan_u(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
+                   int64_t n_waves, hipStream_t st) {
+    const int nkb = p->dp / 16;
+    if (UMAX >= 4 && nkb % 4 == 0)
+        launch_scan_t<T, S, (UMAX >= 4 ? 4 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
+    else if (UMAX >= 2 && nkb % 2 == 0)
+        launch_scan_t<T, S, (UMAX >= 2 ? 2 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
+    else
+        launch_scan_t<T, S, 1>(p, Q, m_valid, dots, dots_stride, n_waves, st);
+}
+
+// raw dots of `m` staged queries (m <= 64) → dots[q*stride + row]
+int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t dots_stride,
+                hipStream_t st) {
+    static const int wpc_env = getenv("CSLAM_SCAN_WPC") ? atoi(getenv("CSLAM_SCAN_WPC")) : 0;
+    static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
+    const int wpc = wpc_env > 0 ? wpc_env : 4;  // measured best at S=4 (profiles/r01_scan_sweep.txt)
+    const int S = s_env > 0 ? s_env : 4;
+    int64_t groups = (p->n + 16 * S - 1) / (16 * S);
+    int64_t resident = (int64_t)p->cus * wpc;
+    int64_t n_waves = groups < resident ? groups : resident;
     if (n_waves < 1) n_waves = 1;
     bool prof = p->prof_on && p->prof_n < p->prof_max;
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    if (m <= 16)
-        launch_scan_t<1, 8>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
-    else if (m <= 32)
-        launch_scan_t<2, 4>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
-    else
-        launch_scan_t<4, 2>(p, Qstage, rnq, m, sims, sims_stride, n_waves, st);
+    if (m <= 16) {
+        if (S == 1)
+            launch_scan_u<1, 1, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        else if (S == 2)
+            launch_scan_u<1, 2, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        else if (S == 8)
+            launch_scan_u<1, 8, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        else
+            launch_scan_u<1, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+    } else if (m <= 32) {
+        launch_scan_u<2, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+    } else {
+        launch_scan_u<4, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+    }
     CSLAM_HIP_TRY(hipGetLastError());
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
@@ -439,34 +511,37 @@ int launch_scan(cslam_pool* p, const float* Qstage, const float* rnq, int m, flo
     return CSLAM_OK;
 }
 
-// sims for queries [0,m) (device, arbitrary stride) into p->sims-like buffer
-int compute_sims(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* sims,
-                 int64_t sims_stride, hipStream_t st) {
+// raw dots for queries [0,m) (device, arbitrary stride), m <= kQueryChunk; also fills
+// p->rnq[0..m) with 1/max(||q||,1e-8)
+int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* dots,
+                 int64_t dots_stride, hipStream_t st) {
+    CSLAM_TRY(p->qstage.reserve((size_t)kMaxQueriesPerPass * p->dp * sizeof(float)));
+    CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
     for (int q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
         int mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
         int mq_pad = mb <= 16 ? 16 : (mb <= 32 ? 32 : 64);
-        // double-buffer the staging area by pass parity so pass i+1's staging does not
-        // overwrite what pass i's scan is still reading is guaranteed by stream order already.
-        CSLAM_TRY(p->qstage.reserve((size_t)kMaxQueriesPerPass * p->dp * sizeof(float)));
-        CSLAM_TRY(p->rnq.reserve((size_t)kMaxQueriesPerPass * sizeof(float)));
+        // the staging area is reused by every pass: stream order keeps pass i+1's staging
+        // behind pass i's scan
         hipLaunchKernelGGL(k_stage_queries, dim3((mq_pad + 3) / 4), dim3(256), 0, st,
                            q_dev + (int64_t)q0 * q_stride, q_stride, p->dim, mb, mq_pad, p->dp,
-                           p->qstage.as<float>(), p->rnq.as<float>());
+                           p->qstage.as<float>(), p->rnq.as<float>() + q0);
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), p->rnq.as<float>(), mb,
-                              sims + (int64_t)q0 * sims_stride, sims_stride, st));
+        CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), mb, dots + (int64_t)q0 * dots_stride,
+                              dots_stride, st));
     }
     return CSLAM_OK;
 }
 
 int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
                    int32_t* out_idx, float* out_sim, hipStream_t st) {
+    const float* rnx = p->inv_norm;
+    const float* rnq = p->rnq.as<float>();
     int64_t n_in = p->n;
     int64_t parts = (n_in + kSelectPart - 1) / kSelectPart;
     if (parts <= 1) {
         hipLaunchKernelGGL((k_select<true, true>), dim3(1, m), dim3(256), 0, st, sims,
-                           sims_stride, nullptr, (int64_t)0, n_in, k, nullptr, (int64_t)0,
-                           out_idx, out_sim);
+                           sims_stride, rnx, rnq, nullptr, (int64_t)0, n_in, k, nullptr,
+                           (int64_t)0, out_idx, out_sim);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -474,8 +549,8 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
     int64_t cstride = parts * k;
     CSLAM_TRY(p->cand_a.reserve((size_t)m * cstride * sizeof(uint64_t)));
     hipLaunchKernelGGL((k_select<true, false>), dim3((unsigned)parts, m), dim3(256), 0, st, sims,
-                       sims_stride, nullptr, (int64_t)0, n_in, k, p->cand_a.as<uint64_t>(),
-                       cstride, nullptr, nullptr);
+                       sims_stride, rnx, rnq, nullptr, (int64_t)0, n_in, k,
+                       p->cand_a.as<uint64_t>(), cstride, nullptr, nullptr);
     CSLAM_HIP_TRY(hipGetLastError());
     DevBuf* src = &p->cand_a;
     DevBuf* dst = &p->cand_b;
@@ -485,16 +560,16 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
         parts = (n_in + kSelectPart - 1) / kSelectPart;
         if (parts <= 1) {
             hipLaunchKernelGGL((k_select<false, true>), dim3(1, m), dim3(256), 0, st, nullptr,
-                               (int64_t)0, src->as<uint64_t>(), in_stride, n_in, k, nullptr,
-                               (int64_t)0, out_idx, out_sim);
+                               (int64_t)0, nullptr, nullptr, src->as<uint64_t>(), in_stride, n_in,
+                               k, nullptr, (int64_t)0, out_idx, out_sim);
             CSLAM_HIP_TRY(hipGetLastError());
             return CSLAM_OK;
         }
         int64_t ostride = parts * k;
         CSLAM_TRY(dst->reserve((size_t)m * ostride * sizeof(uint64_t)));
         hipLaunchKernelGGL((k_select<false, false>), dim3((unsigned)parts, m), dim3(256), 0, st,
-                           nullptr, (int64_t)0, src->as<uint64_t>(), in_stride, n_in, k,
-                           dst->as<uint64_t>(), ostride, nullptr, nullptr);
+                           nullptr, (int64_t)0, nullptr, nullptr, src->as<uint64_t>(), in_stride,
+                           n_in, k, dst->as<uint64_t>(), ostride, nullptr, nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         DevBuf* t = src;
         src = dst;
@@ -506,13 +581,15 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
 
 int select_any_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
                  int32_t* out_idx, float* out_sim, hipStream_t st) {
+    const float* rnx = p->inv_norm;
+    const float* rnq = p->rnq.as<float>();
     int64_t npow2 = 1;
     while (npow2 < p->n) npow2 <<= 1;
     if (npow2 < 2) npow2 = 2;
     CSLAM_TRY(p->comp.reserve((size_t)m * npow2 * sizeof(uint64_t)));
     uint64_t* comp = p->comp.as<uint64_t>();
     hipLaunchKernelGGL(k_make_comp, dim3((unsigned)((npow2 + 255) / 256), m), dim3(256), 0, st,
-                       sims, sims_stride, p->n, npow2, comp);
+                       sims, sims_stride, rnx, rnq, p->n, npow2, comp);
     for (int64_t size = 2; size <= npow2; size <<= 1)
         for (int64_t stride = size >> 1; stride > 0; stride >>= 1)
             hipLaunchKernelGGL(k_bitonic_step, dim3((unsigned)((npow2 / 2 + 255) / 256), m),
@@ -539,7 +616,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     float* sims = p->sims.as<float>();
     for (int q0 = 0; q0 < m; q0 += (int)kQueryChunk) {
         int mb = m - q0 < (int)kQueryChunk ? m - q0 : (int)kQueryChunk;
-        CSLAM_TRY(compute_sims(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,
+        CSLAM_TRY(compute_dots(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,
                                st));
         if (k <= kSelectMaxK)
             CSLAM_TRY(select_small_k(p, sims, sims_stride, mb, k, out_idx + (int64_t)q0 * k,
@@ -566,6 +643,11 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
     cslam_pool* p = new cslam_pool();
     p->dim = dim;
     p->dp = (int)pad16(dim);
+    {
+        const char* e = getenv("CSLAM_ROW_PAD");
+        int64_t pad = e ? atoll(e) : 0;
+        p->xs = p->dp + (pad > 0 ? pad16(pad) : 0);
+    }
     p->device = device_id;
     int rc = device_cu_count(device_id, &p->cus);
     if (rc != CSLAM_OK) {
@@ -612,7 +694,7 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, p->stream));
-    CSLAM_HIP_TRY(hipMemcpy2DAsync(p->rows + p->n * p->dp, (size_t)p->dp * sizeof(float), rows,
+    CSLAM_HIP_TRY(hipMemcpy2DAsync(p->rows + p->n * p->xs, (size_t)p->xs * sizeof(float), rows,
                                    (size_t)p->dim * sizeof(float), (size_t)p->dim * sizeof(float),
                                    (size_t)n_rows, hipMemcpyHostToDevice, p->stream));
     CSLAM_TRY(launch_norms(p, p->n, n_rows, p->stream));
@@ -630,7 +712,7 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
     hipStream_t st = stream ? (hipStream_t)stream : p->stream;
     CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
     hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
-                       row_stride, p->dim, p->rows + p->n * p->dp, (int64_t)p->dp, p->dp, n_rows);
+                       row_stride, p->dim, p->rows + p->n * p->xs, p->xs, p->dp, n_rows);
     CSLAM_HIP_TRY(hipGetLastError());
     CSLAM_TRY(launch_norms(p, p->n, n_rows, st));
     p->n += n_rows;
@@ -648,8 +730,8 @@ int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float*
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
-    CSLAM_HIP_TRY(hipMemcpy2D(out, (size_t)p->dim * sizeof(float), p->rows + first * p->dp,
-                              (size_t)p->dp * sizeof(float), (size_t)p->dim * sizeof(float),
+    CSLAM_HIP_TRY(hipMemcpy2D(out, (size_t)p->dim * sizeof(float), p->rows + first * p->xs,
+                              (size_t)p->xs * sizeof(float), (size_t)p->dim * sizeof(float),
                               (size_t)n, hipMemcpyDeviceToHost));
     return CSLAM_OK;
 }
@@ -668,7 +750,7 @@ int cslam_pool_read_inv_norms(const cslam_pool_t* p, int64_t first, int64_t n, f
 int cslam_pool_device_view(const cslam_pool_t* p, const float** rows_dev, int64_t* row_stride) {
     if (!p || !rows_dev || !row_stride) return fail(CSLAM_E_INVALID, "pool_device_view: bad args");
     *rows_dev = p->rows;
-    *row_stride = p->dp;
+    *row_stride = p->xs;
     return CSLAM_OK;
 }
 
@@ -693,7 +775,16 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
     if (n_queries == 0 || p->n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = stream ? (hipStream_t)stream : p->stream;
-    return compute_sims(p, queries_dev, query_stride, n_queries, sims_dev, sims_stride, st);
+    for (int q0 = 0; q0 < n_queries; q0 += (int)kQueryChunk) {
+        int mb = n_queries - q0 < (int)kQueryChunk ? n_queries - q0 : (int)kQueryChunk;
+        float* out = sims_dev + (int64_t)q0 * sims_stride;
+        CSLAM_TRY(compute_dots(p, queries_dev + (int64_t)q0 * query_stride, query_stride, mb, out,
+                               sims_stride, st));
+        hipLaunchKernelGGL(k_scale, dim3((unsigned)((p->n + 255) / 256), mb), dim3(256), 0, st, out,
+                           sims_stride, p->n, p->inv_norm, p->rnq.as<float>());
+        CSLAM_HIP_TRY(hipGetLastError());
+    }
+    return CSLAM_OK;
 }
 
 int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int k,
