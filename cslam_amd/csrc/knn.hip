@@ -29,6 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kChunkKb = 32;       // fold the MFMA partial into the total every 32 k-blocks
 constexpr int kSelectPart = 4096;  // elements per select block (256 threads x 16)
 constexpr int kSelectMaxK = 128;   // above this the bitonic path is used
 constexpr int kMaxQueriesPerPass = 64;
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
 //   lane l: r = l & 15 (row in strip / query column), g = l >> 4 (k slot)
 //   A_s = X[row(s,r)][16kb + 4g .. +3], B_t = Q[col 16t + r][16kb + 4g .. +3]; MFMA j consumes
 //   component j → chain order inside a 16-block: k = 16kb + 4g + j, j outer, g inner
-//   (DESIGN.md §3); every output is ONE chain, whatever T/S/U.
+//   (DESIGN.md §3); the chain restarts every 512 floats (32 k-blocks) and the chunk partials
+//   are folded into a running total by plain fp32 adds — identical for every T/S/U.
 //   Both operands run through a U-deep register ring that is refilled right after use and
 //   keeps running ACROSS group boundaries, so a wave always has U*S KiB of X in flight.  The
 //   loop body is branch-free apart from the group epilogue (stores only), which lets the
@@ -183,11 +185,25 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
 
     f32x4 a[U][S];
     f32x4 b[U][T];
-    f32x4 acc[S][T];
+    f32x4 acc[S][T];  // partial of the current 512-float chunk (MFMA accumulator)
+    f32x4 tot[S][T];  // running total of the folded chunks
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int fold_turns = kChunkKb / U;  // U divides 32
+    auto fold = [&]() {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                tot[s][t] = tot[s][t] + acc[s][t];
+                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
 
     auto store_group = [&](int64_t grp) {
 #pragma unroll
@@ -200,9 +216,9 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
                     float* out = dots + (int64_t)q * dots_stride + r0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (r0 + e < hi) out[e] = acc[s][t][e];
+                        if (r0 + e < hi) out[e] = tot[s][t][e];
                 }
-                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
 #pragma unroll
             for (int t = 0; t < T; ++t) b[u][t] = qp[t][qn + u * 4];
         }
+        if (nturn == 0 || nturn % fold_turns == 0) fold();
         if (nturn == 0) store_group(grp);
         grp = ngrp;
         turn = nturn;
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
     // last ring turn: nothing left to prefetch
 #pragma unroll
     for (int u = 0; u < U; ++u) mfma_slot(u);
+    fold();
     store_group(grp);
 }
 

@@ -14,9 +14,13 @@
  * Numeric contract (what "bit-exact" means for the HIP path):
  *   the reference leaves the fp32 summation order to torch; this restatement pins ONE order
  *   so that indices and similarities are reproducible bit for bit:
- *     dot(x,q)  : a single fmaf chain, k visited in 16-blocks, inside a block
- *                 k = kb + 4*g + j for j=0..3 (outer), g=0..3 (inner)   — the order in which
- *                 v_mfma_f32_16x16x4_f32 consumes a lane's float4 operand
+ *     dot(x,q)  : k is cut into chunks of 512 floats; inside a chunk ONE fmaf chain, k visited
+ *                 in 16-blocks, inside a block k = kb + 4*g + j for j=0..3 (outer), g=0..3
+ *                 (inner) — the order in which v_mfma_f32_16x16x4_f32 consumes a lane's
+ *                 float4 operand; chunk partials are added to the total in chunk order
+ *                 (plain fp32 adds).  The chunking keeps |sim - fp64 cosine| < 4e-7 at
+ *                 D = 4096 (a single 4096-long chain drifts to 2.4e-6, beyond the 1e-6 tie
+ *                 tolerance of the reference's own test)
  *     ||x||^2   : 64 interleaved partial fmaf chains (lane l takes floats 256*t + 4*l + c),
  *                 combined by an xor-butterfly (32,16,8,4,2,1)           — a wave64 reduction
  *     rn(x)     : 1 / max(sqrt(||x||^2), 1e-8)     (IEEE sqrt and divide)
@@ -72,19 +76,27 @@ static float inv_norm(const float* x, int64_t d) {
     return 1.0f / nrm;
 }
 
-/* dot(x,q) as one fmaf chain in MFMA-16x16x4 operand order. */
+/* dot(x,q): fmaf chains in MFMA-16x16x4 operand order over chunks of 512 floats (32 k-blocks),
+ * chunk partials folded into the total by plain fp32 adds in chunk order. */
+#define ORACLE_CHUNK_KB 32
 static float dot_chain(const float* x, const float* q, int64_t d) {
-    float acc = 0.0f;
+    float total = 0.0f, part = 0.0f;
     int64_t dp = pad16(d);
-    for (int64_t kb = 0; kb < dp; kb += 16)
+    int64_t nkb = dp / 16;
+    for (int64_t kb = 0; kb < nkb; ++kb) {
         for (int j = 0; j < 4; ++j)
             for (int g = 0; g < 4; ++g) {
-                int64_t k = kb + 4 * g + j;
+                int64_t k = kb * 16 + 4 * g + j;
                 float a = (k < d) ? x[k] : 0.0f;
                 float b = (k < d) ? q[k] : 0.0f;
-                acc = fmaf(a, b, acc);
+                part = fmaf(a, b, part);
             }
-    return acc;
+        if ((kb + 1) % ORACLE_CHUNK_KB == 0 || kb + 1 == nkb) {
+            total = total + part;
+            part = 0.0f;
+        }
+    }
+    return total;
 }
 
 /* 1/max(||row||,1e-8) for n rows of length d (dense, stride d). */

@@ -1,0 +1,384 @@
+#!/usr/bin/env python
+"""Generates the golden vectors under tests/golden/ by RUNNING THE REFERENCE (nhahn/cslam at
+/root/reference) on seeded inputs.  Build-container only: the reference never travels to the
+GPU box, only the .npz/.json written here do.
+
+Shims (all outside /root/reference):
+  * `numba` stub (cslam/mac/mac.py:12-13 and utils.py:9-10 import it, never use it)
+  * NearestNeighborsMatching.device forced to CPU right after construction
+    (cslam/nns_matching.py:16 hard-wires 'cuda')
+  * fake `node` with get_logger() for LoopClosureSparseMatching (lcsm.py:72)
+
+Usage:  python tests/golden/gen_golden.py
+"""
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import types
+from collections import namedtuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _install_shims():
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    nb.njit = nb.jit
+    ex = types.ModuleType("numba.experimental")
+    ex.jitclass = lambda *a, **k: (lambda c: c)
+    nb.experimental = ex
+    sys.modules["numba"] = nb
+    sys.modules["numba.experimental"] = ex
+    sys.path.insert(0, REF)
+
+
+_install_shims()
+import torch  # noqa: E402
+from cslam.algebraic_connectivity_maximization import (  # noqa: E402
+    AlgebraicConnectivityMaximization, EdgeInterRobot)
+from cslam.loop_closure_sparse_matching import LoopClosureSparseMatching  # noqa: E402
+from cslam.mac.mac import MAC  # noqa: E402
+from cslam.nns_matching import NearestNeighborsMatching  # noqa: E402
+
+GlobalDescriptor = namedtuple("GlobalDescriptor", ["keyframe_id", "robot_id", "descriptor"])
+
+
+class _Logger:
+    def info(self, *a, **k):
+        pass
+
+    debug = error = warn = info
+
+
+class FakeNode:
+    def get_logger(self):
+        return _Logger()
+
+
+def cpu_matcher():
+    m = NearestNeighborsMatching()
+    m.device = torch.device("cpu")
+    return m
+
+
+# ----------------------------------------------------------------------------------------------
+# kNN
+# ----------------------------------------------------------------------------------------------
+def gen_knn():
+    out = {}
+    cases = []
+
+    def add_case(name, X, Q, k):
+        m = cpu_matcher()
+        for i in range(X.shape[0]):
+            m.add_item(X[i], i)
+        idx = np.full((Q.shape[0], k), -1, np.int32)
+        sim = np.full((Q.shape[0], k), -np.inf, np.float32)
+        for qi in range(Q.shape[0]):
+            items, s = m.search(Q[qi], k)
+            idx[qi, :len(items)] = items
+            sim[qi, :len(items)] = s
+        out[f"{name}_X"] = X
+        out[f"{name}_Q"] = Q
+        out[f"{name}_idx"] = idx
+        out[f"{name}_sim"] = sim
+        out[f"{name}_k"] = np.int32(k)
+        cases.append(name)
+
+    rs = np.random.RandomState(0)
+    X = rs.rand(1000, 128).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    add_case("cfg1_unit128", X, rs.rand(16, 128).astype(np.float32), 10)
+
+    X = rs.rand(100, 100).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = rs.rand(10, 100).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    add_case("test_similarity_100", X, Q, 100)  # tests/test_sparse_matching.py:51-81 shape
+
+    X = rs.rand(96, 4096).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    add_case("cfg2_slice4096", X, rs.rand(4, 4096).astype(np.float32), 10)
+
+    X = (rs.randn(400, 37) * 2.5).astype(np.float32)
+    add_case("raw_randn37", X, rs.randn(6, 37).astype(np.float32), 7)
+
+    X = rs.rand(64, 16).astype(np.float32)
+    X[5] = 0.0          # zero row → similarity 0 (eps clamp)
+    X[9] = X[3]         # duplicate rows → exact tie
+    X[40] = 2.0 * X[3]  # scaled duplicate → tie up to rounding
+    add_case("ties_zero16", X, np.vstack([X[3], rs.rand(16)]).astype(np.float32), 5)
+
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "knn_ref.npz"), **out)
+    print("knn_ref.npz:", cases)
+
+
+# ----------------------------------------------------------------------------------------------
+# MAC
+# ----------------------------------------------------------------------------------------------
+def build_multi_robot_graph(rs, nb_poses, nb_cand, nb_robots, random_weights=True):
+    """tests/test_algebraic_connectivity.py:38-74 with a seeded RNG and generic weights."""
+    fixed = [EdgeInterRobot(i, nb_poses - 1, i + 1, nb_poses - 1, 1.0)
+             for i in range(nb_robots - 1)]
+    cand = {}
+    while len(cand) < nb_cand:
+        r0 = int(rs.randint(nb_robots))
+        r1 = int(rs.choice([r for r in range(nb_robots) if r != r0]))
+        w = float(rs.rand()) if random_weights else 1.0
+        e = EdgeInterRobot(r0, int(rs.randint(nb_poses)), r1, int(rs.randint(nb_poses)), w)
+        if e.robot0_id < e.robot1_id:
+            key = (e.robot0_id, e.robot0_keyframe_id, e.robot1_id, e.robot1_keyframe_id)
+        else:
+            key = (e.robot1_id, e.robot1_keyframe_id, e.robot0_id, e.robot0_keyframe_id)
+        cand[key] = e
+    return fixed, list(cand.values())
+
+
+def edges_to_array(edges):
+    return np.array([[e.robot0_id, e.robot0_keyframe_id, e.robot1_id, e.robot1_keyframe_id,
+                      e.weight] for e in edges], dtype=np.float64).reshape(-1, 5)
+
+
+def gen_mac():
+    out = {}
+    cases = []
+    specs = [("g3x10", 10, 40, 3, 5), ("g3x100", 100, 300, 3, 20),
+             ("g2x1000", 1000, 2000, 2, 100), ("g5x200", 200, 1500, 5, 50)]
+    for name, nb_poses, nb_cand, nb_robots, k in specs:
+        rs = np.random.RandomState(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+        fixed, cand = build_multi_robot_graph(rs, nb_poses, nb_cand, nb_robots)
+        in_range = {i: True for i in range(nb_robots)}
+
+        # (1) end-to-end select_candidates on the reference
+        acm = AlgebraicConnectivityMaximization(0, nb_robots)
+        acm.set_graph(list(fixed), list(cand))
+        with contextlib.redirect_stdout(io.StringIO()):
+            selected = acm.select_candidates(k, dict(in_range))
+
+        # (2) the same problem opened up: rekeyed edge arrays + instrumented fw_subset
+        acm2 = AlgebraicConnectivityMaximization(0, nb_robots)
+        acm2.set_graph(list(fixed), list(cand))
+        inc = acm2.check_graph_disconnections(dict(in_range))
+        acm2.compute_offsets(inc)
+        rf = acm2.rekey_edges(acm2.fixed_edges, inc)
+        rf.extend(acm2.fill_odometry())
+        rc = acm2.rekey_edges(acm2.candidate_edges.values(), inc)
+        total = sum(acm2.nb_poses.values())
+        w_init = acm2.greedy_initialization(k, rc)
+        mac = MAC(rf, rc, total)
+        trace = []
+        orig = mac.evaluate_fiedler_pair
+
+        def spy(w, method="tracemin_lu", tol=1e-8, _orig=orig, _trace=trace):
+            f, v = _orig(w, method, tol)
+            _trace.append((np.array(w, dtype=np.float64), float(f), np.array(v)))
+            return f, v
+
+        mac.evaluate_fiedler_pair = spy
+        with contextlib.redirect_stdout(io.StringIO()):
+            rounded, relaxed, upper = mac.fw_subset(w_init, k, max_iters=20)
+        L0 = mac.combined_laplacian(trace[0][0]).tocsr()
+        L0.sum_duplicates()
+        L0.sort_indices()
+        Llast = mac.combined_laplacian(trace[-1][0]).tocsr()
+        Llast.sort_indices()
+        v0 = trace[0][2]
+        v0 = v0 if v0[np.argmax(np.abs(v0))] >= 0 else -v0
+        vl = trace[-1][2]
+        vl = vl if vl[np.argmax(np.abs(vl))] >= 0 else -vl
+        g0 = mac.grad_from_fiedler(trace[0][2])
+
+        out[f"{name}_nb"] = np.array([nb_poses, nb_cand, nb_robots, k, total], np.int64)
+        out[f"{name}_fixed_edges"] = edges_to_array(fixed)
+        out[f"{name}_cand_edges"] = edges_to_array(cand)
+        out[f"{name}_selected"] = edges_to_array(selected)
+        out[f"{name}_fi"] = np.array([e.i for e in rf], np.int32)
+        out[f"{name}_fj"] = np.array([e.j for e in rf], np.int32)
+        out[f"{name}_fw"] = np.array([e.weight for e in rf], np.float64)
+        out[f"{name}_ci"] = np.array([e.i for e in rc], np.int32)
+        out[f"{name}_cj"] = np.array([e.j for e in rc], np.int32)
+        out[f"{name}_cw"] = np.array([e.weight for e in rc], np.float64)
+        out[f"{name}_w_init"] = w_init
+        out[f"{name}_lambda_trace"] = np.array([t[1] for t in trace])
+        out[f"{name}_w_last"] = trace[-1][0]
+        out[f"{name}_L0_indptr"] = L0.indptr.astype(np.int32)
+        out[f"{name}_L0_indices"] = L0.indices.astype(np.int32)
+        out[f"{name}_L0_data"] = L0.data
+        out[f"{name}_v0"] = v0
+        out[f"{name}_vlast"] = vl
+        out[f"{name}_g0"] = g0
+        out[f"{name}_rounded"] = rounded
+        out[f"{name}_relaxed"] = relaxed
+        out[f"{name}_upper"] = np.float64(upper)
+        # cross-check named by BASELINE.json cfg3: scipy eigsh shift-invert on the last L(w)
+        import scipy.sparse.linalg as spla
+        ev = spla.eigsh(Llast.tocsc(), 2, sigma=-1e-6, which="LM", return_eigenvectors=False)
+        out[f"{name}_eigsh_lambda_last"] = np.float64(np.sort(ev)[1])
+        cases.append(name)
+        print(name, "iters", len(trace), "lambda0", trace[0][1], "last", trace[-1][1], "eigsh",
+              float(np.sort(ev)[1]), "selected", len(selected))
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "mac_ref.npz"), **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# AlgebraicConnectivityMaximization bookkeeping traces (quirks of SURVEY.md Appendix A)
+# ----------------------------------------------------------------------------------------------
+def _edge_list(edges):
+    return [[int(e.robot0_id), int(e.robot0_keyframe_id), int(e.robot1_id),
+             int(e.robot1_keyframe_id), float(e.weight)] for e in edges]
+
+
+def gen_acm():
+    traces = {}
+
+    # (a) greedy branch: no fixed inter-robot edge (tests/test_sparse_matching.py:110-207 path)
+    rs = np.random.RandomState(21)
+    acm = AlgebraicConnectivityMaximization(0, 3)
+    ops = []
+    for _ in range(60):
+        r1 = int(rs.randint(1, 3))
+        e = EdgeInterRobot(0, int(rs.randint(50)), r1, int(rs.randint(50)), float(rs.rand()))
+        acm.add_match(e)
+        ops.append(["add_match", _edge_list([e])[0]])
+    sel = acm.select_candidates(10, {0: True, 1: True, 2: True})
+    traces["greedy_no_fixed"] = dict(robot_id=0, max_nb_robots=3, ops=ops, budget=10,
+                                     in_range={"0": True, "1": True, "2": True},
+                                     selected=_edge_list(sel),
+                                     remaining=len(acm.candidate_edges))
+
+    # (b) add_match orientation quirk (acm.py:564-571 vs :84-89)
+    acm = AlgebraicConnectivityMaximization(1, 2)
+    acm.add_match(EdgeInterRobot(1, 5, 0, 7, 0.9))
+    acm.add_match(EdgeInterRobot(1, 5, 0, 7, 0.2))
+    q1 = {str(k): v.weight for k, v in acm.candidate_edges.items()}
+    acm = AlgebraicConnectivityMaximization(0, 2)
+    acm.add_match(EdgeInterRobot(0, 7, 1, 5, 0.9))
+    acm.add_match(EdgeInterRobot(0, 7, 1, 5, 0.2))
+    q2 = {str(k): v.weight for k, v in acm.candidate_edges.items()}
+    traces["add_match_quirk"] = dict(robot1_first=q1, robot0_first=q2)
+
+    # (c) excluded robot → disconnected L → exception ladder → greedy w_init
+    rs = np.random.RandomState(33)
+    np.random.seed(1234)  # pseudo_greedy_initialization uses the global RNG (acm.py:236)
+    fixed = [EdgeInterRobot(0, 19, 1, 19, 1.0)]
+    cand = []
+    seen = set()
+    while len(cand) < 30:
+        e = EdgeInterRobot(0, int(rs.randint(20)), 1, int(rs.randint(20)), float(rs.rand()))
+        if (e.robot0_keyframe_id, e.robot1_keyframe_id) in seen:
+            continue
+        seen.add((e.robot0_keyframe_id, e.robot1_keyframe_id))
+        cand.append(e)
+    cand.append(EdgeInterRobot(0, 3, 2, 4, 0.5))  # robot 2 known (5 poses) but out of range
+    acm = AlgebraicConnectivityMaximization(0, 3)
+    acm.set_graph(list(fixed), list(cand))
+    with contextlib.redirect_stdout(io.StringIO()):
+        sel = acm.select_candidates(5, {0: True, 1: True, 2: False})
+    traces["excluded_robot"] = dict(robot_id=0, max_nb_robots=3, fixed=_edge_list(fixed),
+                                    cand=_edge_list(cand), budget=5,
+                                    in_range={"0": True, "1": True, "2": False},
+                                    selected=_edge_list(sel),
+                                    remaining=len(acm.candidate_edges))
+
+    # (d) full life-cycle: select → candidate_edges_to_fixed / remove(failed) → select again
+    rs = np.random.RandomState(44)
+    fixed, cand = build_multi_robot_graph(rs, 60, 200, 3)
+    acm = AlgebraicConnectivityMaximization(0, 3)
+    acm.set_graph(list(fixed), list(cand))
+    rounds = []
+    for rd in range(3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sel = acm.select_candidates(8, {0: True, 1: True, 2: True})
+        ok = [e for i, e in enumerate(sel) if i % 2 == 0]
+        bad = [e for i, e in enumerate(sel) if i % 2 == 1]
+        rounds.append(dict(selected=_edge_list(sel)))
+        acm.candidate_edges_to_fixed(list(ok))
+        acm.remove_candidate_edges(list(bad), failed=True)
+        rounds[-1]["nb_fixed"] = len(acm.fixed_edges)
+        rounds[-1]["nb_cand"] = len(acm.candidate_edges)
+    traces["lifecycle"] = dict(robot_id=0, max_nb_robots=3, fixed=_edge_list(fixed),
+                               cand=_edge_list(cand), budget=8, rounds=rounds)
+
+    # (e) budget larger than #candidates (acm.py:495-496) and connection-biased greedy with one
+    #     robot lacking a fixed edge (acm.py:256-288)
+    rs = np.random.RandomState(55)
+    fixed = [EdgeInterRobot(0, 9, 1, 9, 1.0)]
+    cand = []
+    for _ in range(12):
+        cand.append(EdgeInterRobot(0, int(rs.randint(10)), 1, int(rs.randint(10)), float(rs.rand())))
+    for _ in range(6):
+        cand.append(EdgeInterRobot(1, int(rs.randint(10)), 2, int(rs.randint(10)), float(rs.rand())))
+    acm = AlgebraicConnectivityMaximization(0, 3)
+    acm.set_graph(list(fixed), list(cand))
+    sel = acm.select_candidates(4, {0: True, 1: True, 2: True})
+    acm_b = AlgebraicConnectivityMaximization(0, 3)
+    acm_b.set_graph(list(fixed), list(cand))
+    sel_b = acm_b.select_candidates(500, {0: True, 1: True, 2: True})
+    traces["connection_biased"] = dict(robot_id=0, max_nb_robots=3, fixed=_edge_list(fixed),
+                                       cand=_edge_list(cand), budget=4,
+                                       selected=_edge_list(sel),
+                                       selected_big_budget=_edge_list(sel_b))
+
+    with open(os.path.join(HERE, "acm_ref.json"), "w") as f:
+        json.dump(traces, f)
+    print("acm_ref.json:", list(traces))
+
+
+# ----------------------------------------------------------------------------------------------
+# LoopClosureSparseMatching end to end (cfg1-shaped, reduced)
+# ----------------------------------------------------------------------------------------------
+def gen_lcsm():
+    def params(robot_id, nb, thr=0.0):
+        return {"robot_id": robot_id, "max_nb_robots": nb, "frontend.sensor_type": "stereo",
+                "frontend.similarity_threshold": thr, "frontend.nb_best_matches": 10,
+                "frontend.intra_loop_min_inbetween_keyframes": 10,
+                "frontend.enable_sparsification": True,
+                "evaluation.enable_sparsification_comparison": False}
+
+    def make(p):
+        l = LoopClosureSparseMatching(p, FakeNode())
+        l.local_nnsm.device = torch.device("cpu")
+        for m in l.other_robots_nnsm.values():
+            m.device = torch.device("cpu")
+        return l
+
+    rs = np.random.RandomState(7)
+    nb_robots, nkf, dim = 3, 120, 64
+    desc = rs.rand(nb_robots, nkf, dim).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=2, keepdims=True)
+    l = make(params(0, nb_robots, thr=0.6))
+    events = []
+    for kf in range(nkf):
+        ms = l.add_local_global_descriptor(desc[0, kf], kf)
+        events.append(["local", kf, _edge_list(ms)])
+        kf_match, sims = l.match_local_loop_closures(desc[0, kf], kf)
+        events.append(["intra", kf, None if kf_match is None else int(kf_match),
+                       [float(s) for s in sims]])
+        for r in (1, 2):
+            m = l.add_other_robot_global_descriptor(
+                GlobalDescriptor(kf, r, desc[r, kf].tolist()))
+            events.append(["other", r, kf, None if m is None else _edge_list([m])[0]])
+    cand = {str(k): float(v.weight) for k, v in l.candidate_selector.candidate_edges.items()}
+    sel = l.select_candidates(10, {0: True, 1: True, 2: True})
+    np.savez_compressed(os.path.join(HERE, "lcsm_desc.npz"), desc=desc)
+    with open(os.path.join(HERE, "lcsm_ref.json"), "w") as f:
+        json.dump(dict(params=params(0, nb_robots, thr=0.6), events=events, candidates=cand,
+                       selected=_edge_list(sel)), f)
+    print("lcsm_ref.json: events", len(events), "candidates", len(cand), "selected", len(sel))
+
+
+if __name__ == "__main__":
+    random.seed(0)
+    np.random.seed(0)
+    gen_knn()
+    gen_mac()
+    gen_acm()
+    gen_lcsm()
