@@ -102,38 +102,66 @@ __global__ __launch_bounds__(256) void k_copy_pad(const float* __restrict__ src,
     for (int k = lane; k < dp; k += 64) d[k] = (k < dim) ? s[k] : 0.0f;
 }
 
-// queries → staging [mq_pad][dp] (zero padded, rows >= m are zero) and rnq[mq_pad]
+// queries → staging [mq_pad][dp] (zero padded, rows >= m are zero) and rnq[mq_pad].
+// One 256-thread block per query row; wave 0 also computes ||q||^2 in wave64 order straight
+// from the source values (loads batched 8 deep: the chain order is per lane, not per load).
+__device__ inline float ld_or_zero(const float* s, int k, int dim) { return k < dim ? s[k] : 0.0f; }
+
 __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__ q,
                                                        int64_t q_stride, int dim, int m,
                                                        int mq_pad, int dp,
                                                        float* __restrict__ stage,
-                                                       float* __restrict__ rnq) {
-    int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
+                                                       float* __restrict__ rnq, int vec_ok) {
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x;
     if (w >= mq_pad) return;
     float* d = stage + (int64_t)w * dp;
-    if (w < m) {
-        const float* s = q + (int64_t)w * q_stride;
-        for (int k = lane; k < dp; k += 64) d[k] = (k < dim) ? s[k] : 0.0f;
-    } else {
-        for (int k = lane; k < dp; k += 64) d[k] = 0.0f;
+    if (w >= m) {
+        for (int k = tid * 4; k < dp; k += 1024)
+            *reinterpret_cast<f32x4*>(d + k) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid == 0) rnq[w] = 0.0f;
+        return;
     }
-    // ||q||^2 straight from the source values, in the same wave64 order as wave_sumsq
-    float ss = 0.0f;
-    if (w < m) {
-        const float* s = q + (int64_t)w * q_stride;
-        for (int base = 4 * lane; base < dp; base += 256) {
+    const float* s = q + (int64_t)w * q_stride;
+    for (int k = tid * 4; k < dp; k += 1024) {
+        f32x4 v;
+        if (vec_ok && k + 3 < dim)
+            v = *reinterpret_cast<const f32x4*>(s + k);
+        else
+            v = f32x4{ld_or_zero(s, k, dim), ld_or_zero(s, k + 1, dim), ld_or_zero(s, k + 2, dim),
+                      ld_or_zero(s, k + 3, dim)};
+        *reinterpret_cast<f32x4*>(d + k) = v;
+    }
+    if (tid < 64) {
+        const int lane = tid;
+        float ss = 0.0f;
+        for (int base0 = 4 * lane; base0 < dp; base0 += 256 * 8) {
+            f32x4 v[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int k = base + c;
-                float v = (k < dim) ? s[k] : 0.0f;
-                ss = __builtin_fmaf(v, v, ss);
+            for (int u = 0; u < 8; ++u) {
+                const int k = base0 + 256 * u;
+                if (k < dp) {
+                    if (vec_ok && k + 3 < dim)
+                        v[u] = *reinterpret_cast<const f32x4*>(s + k);
+                    else
+                        v[u] = f32x4{ld_or_zero(s, k, dim), ld_or_zero(s, k + 1, dim),
+                                     ld_or_zero(s, k + 2, dim), ld_or_zero(s, k + 3, dim)};
+                } else {
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // fmaf(0,0,ss) == ss: no-op past the row
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ss = __builtin_fmaf(v[u].x, v[u].x, ss);
+                ss = __builtin_fmaf(v[u].y, v[u].y, ss);
+                ss = __builtin_fmaf(v[u].z, v[u].z, ss);
+                ss = __builtin_fmaf(v[u].w, v[u].w, ss);
             }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, kWave);
+        if (lane == 0) rnq[w] = inv_norm_from_sumsq(ss);
     }
-    if (lane == 0) rnq[w] = (w < m) ? inv_norm_from_sumsq(ss) : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,9 +568,11 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         int mq_pad = mb <= 16 ? 16 : (mb <= 32 ? 32 : 64);
         // the staging area is reused by every pass: stream order keeps pass i+1's staging
         // behind pass i's scan
-        hipLaunchKernelGGL(k_stage_queries, dim3((mq_pad + 3) / 4), dim3(256), 0, st,
-                           q_dev + (int64_t)q0 * q_stride, q_stride, p->dim, mb, mq_pad, p->dp,
-                           p->qstage.as<float>(), p->rnq.as<float>() + q0);
+        const float* qsrc = q_dev + (int64_t)q0 * q_stride;
+        const int vec_ok = ((reinterpret_cast<uintptr_t>(qsrc) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad), dim3(256), 0, st, qsrc, q_stride, p->dim,
+                           mb, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>() + q0,
+                           vec_ok);
         CSLAM_HIP_TRY(hipGetLastError());
         CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), mb, dots + (int64_t)q0 * dots_stride,
                               dots_stride, st));

@@ -1,16 +1,1245 @@
-// mac.hip — placeholder until the device MAC solver lands (next commit).
+// mac.hip — MAC (maximise algebraic connectivity) candidate selection numerics on gfx950.
+//
+// Replaces cslam/mac/mac.py:19-233 and cslam/mac/utils.py:44-122, and the third-party Fiedler
+// solve they call (networkx `tracemin_lu`, mac.py:52-58).  All arithmetic fp64.
+//
+// Data layout (HBM, resident for the life of the handle; cfg3: n = 50k, m = 200k ≈ 12 MB,
+// i.e. L2/MALL-resident — the solver is launch/latency-bound, not HBM-bound):
+//   edge-adjacency CSR  adj_ptr[n+1], adj_nbr[2E], adj_eid[2E]   (E = fixed + candidates, both
+//                       directions; built once in cslam_mac_create)
+//   ew[E]               current weight of every edge: fixed weight, or w_k*c_k (0 when
+//                       w_k <= tol)  ← the only thing L(w) changes between FW iterations
+//   L(w) is never materialised on the device: y = L x is y_i = sum_e ew[e] (x_i - x_nbr(e)),
+//   rows summed in adjacency order (deterministic, no atomics).
+//
+// Fiedler pair: LOBPCG with one vector (3x3 Rayleigh-Ritz over {x, w, p}), constraint x ⟂ 1,
+// preconditioner M = tridiag(L(w)) restricted to the fixed odometry chains (SPD because L is
+// diagonally dominant; parameter-free).  M is factored LDL^T once per solve; M z = r is two
+// first-order linear recurrences = two parallel affine scans.  ~150 iterations at cfg3 scale
+// (vs ~3e5 SpMVs for Jacobi-PCG TraceMIN).  Converged to a TIGHTER residual than
+// the reference's tol so the eigenvector (hence the gradient ranking) is at least as accurate.
+// One iteration = 8 small kernels captured in a hipGraph (16 iterations per replay); the host
+// only polls a `done` word between replays.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
 #include "common.hpp"
+
 using namespace cslam;
-struct cslam_mac { int n; };
-extern "C" {
-#define NI(name) return fail(CSLAM_E_INVALID, name ": not implemented yet")
-int cslam_mac_create(int32_t, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const int32_t*, const double*, int64_t, int, cslam_mac_t**) { NI("cslam_mac_create"); }
-int cslam_mac_destroy(cslam_mac_t*) { return CSLAM_OK; }
-int cslam_mac_laplacian(cslam_mac_t*, const double*, double, int64_t*, int32_t*, int32_t*, double*) { NI("cslam_mac_laplacian"); }
-int cslam_mac_fiedler(cslam_mac_t*, const double*, double, double*, double*, int32_t*) { NI("cslam_mac_fiedler"); }
-int cslam_mac_grad(cslam_mac_t*, const double*, double*) { NI("cslam_mac_grad"); }
-int cslam_topk_mask(const double*, int64_t, int64_t, double*) { NI("cslam_topk_mask"); }
-int cslam_mac_round_tiebreak(cslam_mac_t*, const double*, int64_t, int, double*) { NI("cslam_mac_round_tiebreak"); }
-int cslam_mac_fw_subset(cslam_mac_t*, const double*, int64_t, int, double, double*, double*, double*, int32_t*, double*) { NI("cslam_mac_fw_subset"); }
-int cslam_mac_stats(const cslam_mac_t*, int64_t*, double*) { NI("cslam_mac_stats"); }
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanElems = 4;                       // per thread
+constexpr int kScanBlock = kScanThreads * kScanElems;  // 1024 nodes per scan block
+constexpr int kRedBlocksMax = 256;                  // blocks of the reduction kernels
+constexpr int kIterPerGraph = 16;
+constexpr int kMaxIters = 20000;
+
+struct Scalars {
+    double theta;      // current Rayleigh quotient (Fiedler value estimate)
+    double coef[3];    // x_new = c0 x + c1 w' + c2 p
+    double mu;         // mean of the preconditioned residual (projected out)
+    double lnorm;      // ||L||_inf = max_i 2 L_ii
+    double res;        // ||r||_1 / ||L||_inf   (networkx criterion, algebraicconnectivity.py:243)
+    double tol;
+    double fw_f, fw_u, fw_gap_tol, fw_alpha;
+    unsigned long long lnorm_bits;
+    int done;          // 1 = converged, 2 = breakdown
+    int iters;
+    int max_iters;
+    int fw_done;
+    int factor_bad;
+};
+
+// --------------------------------------------------------------------------------------------
+// block reduction helper (sum of doubles, deterministic order)
+// --------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
+
+template <int NV>
+__device__ inline void block_sum(double (&v)[NV], double* smem /* [NV*4] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[i * 4 + wave] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        v[i] = (smem[i * 4 + 0] + smem[i * 4 + 1]) + (smem[i * 4 + 2] + smem[i * 4 + 3]);
+}
+
+// --------------------------------------------------------------------------------------------
+// L(w) pieces
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_weights(const double* __restrict__ w,
+                                                      const double* __restrict__ cw, int64_t m,
+                                                      double tol, double* __restrict__ ew_cand) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    double wk = w[k];
+    ew_cand[k] = (wk > tol) ? wk * cw[k] : 0.0;  // mac.py:72-73
+}
+
+// a_i = L_ii, b_i = L_{i,i+1} inside a fixed odometry chain (else 0), ||L||_inf
+__global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_ptr,
+                                              const int32_t* __restrict__ adj_nbr,
+                                              const int32_t* __restrict__ adj_eid,
+                                              const double* __restrict__ ew,
+                                              const uint8_t* __restrict__ link, int n,
+                                              double* __restrict__ a, double* __restrict__ b,
+                                              Scalars* sc) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    double ai = 0.0;
+    if (i < n) {
+        double bi = 0.0;
+        const bool lk = (i + 1 < n) && link[i];
+        for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
+            double wgt = ew[adj_eid[e]];
+            ai += wgt;
+            if (lk && adj_nbr[e] == i + 1) bi -= wgt;
+        }
+        a[i] = ai;
+        if (i + 1 < n) b[i] = bi;
+    }
+    // max over the block, then one atomic (positive doubles order like their bit patterns)
+    double mx = ai;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0)
+        atomicMax(&sc->lnorm_bits, (unsigned long long)__double_as_longlong(2.0 * mx));
+}
+
+// LDL^T of the block-tridiagonal M, one thread per chain segment (sequential recurrence)
+__global__ void k_factor(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+                         int nseg, const double* __restrict__ a, const double* __restrict__ b,
+                         double* __restrict__ l, double* __restrict__ invd, Scalars* sc) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    int i0 = seg_start[s], len = seg_len[s];
+    double d = a[i0];
+    bool bad = !(d > 0.0);
+    invd[i0] = 1.0 / d;
+    for (int t = 1; t < len; ++t) {
+        int i = i0 + t;
+        double li = b[i - 1] / d;
+        l[i - 1] = li;
+        d = a[i] - li * b[i - 1];
+        bad |= !(d > 0.0);
+        invd[i] = 1.0 / d;
+    }
+    if (bad) sc->factor_bad = 1;
+}
+
+// --------------------------------------------------------------------------------------------
+// affine scans: v_i = mul_i * v_{i-1} + add_i  (forward), and the mirrored backward sweep
+// --------------------------------------------------------------------------------------------
+struct Aff {
+    double m, c;
+};
+__device__ inline Aff compose(Aff first, Aff then) {  // apply `first`, then `then`
+    return Aff{then.m * first.m, then.m * first.c + then.c};
+}
+
+// inclusive scan of one Aff per thread across the 256-thread block
+__device__ inline Aff block_scan_aff(Aff v, Aff* smem /* [256] */) {
+    const int tid = threadIdx.x;
+    smem[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        Aff o = smem[tid >= off ? tid - off : 0];
+        __syncthreads();
+        if (tid >= off) v = compose(o, v);
+        smem[tid] = v;
+        __syncthreads();
+    }
+    return v;
+}
+
+// element coefficients of the two sweeps
+//   forward  (DIR=0): y_i = r_i - l_{i-1} y_{i-1}            element j = i
+//   backward (DIR=1): z_i = y_i*invd_i - l_i z_{i+1}          element j = n-1-i
+template <int DIR>
+__device__ inline Aff elem(int j, int n, const double* __restrict__ rhs,
+                           const double* __restrict__ l, const double* __restrict__ invd) {
+    if (DIR == 0) {
+        return Aff{j > 0 ? -l[j - 1] : 0.0, rhs[j]};
+    } else {
+        int i = n - 1 - j;
+        return Aff{i + 1 < n ? -l[i] : 0.0, rhs[i] * invd[i]};
+    }
+}
+
+// phase A: composite of every 1024-element block
+template <int DIR>
+__global__ __launch_bounds__(kScanThreads) void k_scan_agg(const double* __restrict__ rhs,
+                                                           const double* __restrict__ l,
+                                                           const double* __restrict__ invd, int n,
+                                                           Aff* __restrict__ agg,
+                                                           const Scalars* sc) {
+    if (sc->done) return;
+    __shared__ Aff smem[kScanThreads];
+    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
+    Aff t{1.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < kScanElems; ++e)
+        if (j0 + e < n) t = compose(t, elem<DIR>(j0 + e, n, rhs, l, invd));
+    Aff inc = block_scan_aff(t, smem);
+    if (threadIdx.x == kScanThreads - 1) agg[blockIdx.x] = inc;
+}
+
+// phase B: prefix over preceding block composites, then the block's own elements.
+// DIR=0 writes y; DIR=1 writes z and per-block partial sums of z (for the mean).
+template <int DIR>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const double* __restrict__ rhs,
+                                                             const double* __restrict__ l,
+                                                             const double* __restrict__ invd,
+                                                             int n, const Aff* __restrict__ agg,
+                                                             double* __restrict__ out,
+                                                             double* __restrict__ psum,
+                                                             const Scalars* sc) {
+    if (sc->done) return;
+    __shared__ Aff smem[kScanThreads];
+    __shared__ double red[4];
+    __shared__ double vin_s;
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int b = 0; b < (int)blockIdx.x; ++b) v = agg[b].m * v + agg[b].c;
+        vin_s = v;
+    }
+    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
+    Aff el[kScanElems];
+    Aff t{1.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < kScanElems; ++e) {
+        el[e] = (j0 + e < n) ? elem<DIR>(j0 + e, n, rhs, l, invd) : Aff{1.0, 0.0};
+        t = compose(t, el[e]);
+    }
+    Aff inc = block_scan_aff(t, smem);  // contains __syncthreads → vin_s visible
+    // exclusive prefix of this thread
+    Aff exc = threadIdx.x > 0 ? smem[threadIdx.x - 1] : Aff{1.0, 0.0};
+    (void)inc;
+    double v = exc.m * vin_s + exc.c;
+    double local = 0.0;
+#pragma unroll
+    for (int e = 0; e < kScanElems; ++e) {
+        if (j0 + e < n) {
+            v = el[e].m * v + el[e].c;
+            const int idx = (DIR == 0) ? (j0 + e) : (n - 1 - (j0 + e));
+            out[idx] = v;
+            local += v;
+        }
+    }
+    (void)red;
+    if (DIR == 1) {
+        double s[1] = {local};
+        block_sum<1>(s, red);
+        if (threadIdx.x == 0) psum[blockIdx.x] = s[0];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// y = L x   (one thread per row; the working set lives in L2)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_ptr,
+                                              const int32_t* __restrict__ adj_nbr,
+                                              const int32_t* __restrict__ adj_eid,
+                                              const double* __restrict__ ew,
+                                              const double* __restrict__ x,
+                                              double* __restrict__ y, int n, const Scalars* sc) {
+    if (sc->done) return;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double xi = x[i];
+    double acc = 0.0;
+    for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e)
+        acc += ew[adj_eid[e]] * (xi - x[adj_nbr[e]]);
+    y[i] = acc;
+}
+
+// --------------------------------------------------------------------------------------------
+// Gram matrices of S = [x, w - mu, p], AS = [Ax, Aw, Ap]: 12 dot products
+//   partial[b][0..5]  = S^T S   (xx, xw, xp, ww, wp, pp)
+//   partial[b][6..11] = S^T AS  (xAx, xAw, xAp, wAw, wAp, pAp)
+// --------------------------------------------------------------------------------------------
+__device__ inline double mean_from_psum(const double* psum, int nscan, int n) {
+    double s = 0.0;
+    for (int b = 0; b < nscan; ++b) s += psum[b];
+    return s / (double)n;
+}
+
+__global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
+                                              const double* __restrict__ w,
+                                              const double* __restrict__ p,
+                                              const double* __restrict__ Ax,
+                                              const double* __restrict__ Aw,
+                                              const double* __restrict__ Ap, int n,
+                                              const double* __restrict__ psum, int nscan,
+                                              int use_mu, double* __restrict__ partial,
+                                              const Scalars* sc) {
+    if (sc->done) return;
+    __shared__ double smem[12 * 4];
+    const double mu = use_mu ? mean_from_psum(psum, nscan, n) : 0.0;
+    double v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double xi = x[i], wi = w[i] - mu, pi = p[i];
+        double axi = Ax[i], awi = Aw[i], api = Ap[i];
+        v[0] += xi * xi;
+        v[1] += xi * wi;
+        v[2] += xi * pi;
+        v[3] += wi * wi;
+        v[4] += wi * pi;
+        v[5] += pi * pi;
+        v[6] += xi * axi;
+        v[7] += xi * awi;
+        v[8] += xi * api;
+        v[9] += wi * awi;
+        v[10] += wi * api;
+        v[11] += pi * api;
+    }
+    block_sum<12>(v, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) partial[blockIdx.x * 12 + i] = v[i];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// 3x3 Rayleigh-Ritz (one thread): smallest eigenpair of  GA c = theta GB c  on the active basis
+// --------------------------------------------------------------------------------------------
+__device__ inline void jacobi_smallest(int k, double A[3][3], double* theta, double u[3]) {
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < k; ++i)
+            for (int j = i + 1; j < k; ++j) off += A[i][j] * A[i][j];
+        double dia = 0.0;
+        for (int i = 0; i < k; ++i) dia += A[i][i] * A[i][i];
+        if (off <= 1e-40 * dia || off == 0.0) break;
+        for (int pi = 0; pi < k; ++pi)
+            for (int qi = pi + 1; qi < k; ++qi) {
+                double apq = A[pi][qi];
+                if (apq == 0.0) continue;
+                double tau = (A[qi][qi] - A[pi][pi]) / (2.0 * apq);
+                double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int r = 0; r < k; ++r) {
+                    double arp = A[r][pi], arq = A[r][qi];
+                    A[r][pi] = c * arp - s * arq;
+                    A[r][qi] = s * arp + c * arq;
+                }
+                for (int r = 0; r < k; ++r) {
+                    double apr = A[pi][r], aqr = A[qi][r];
+                    A[pi][r] = c * apr - s * aqr;
+                    A[qi][r] = s * apr + c * aqr;
+                }
+                for (int r = 0; r < k; ++r) {
+                    double vrp = V[r][pi], vrq = V[r][qi];
+                    V[r][pi] = c * vrp - s * vrq;
+                    V[r][qi] = s * vrp + c * vrq;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < k; ++i)
+        if (A[i][i] < A[best][best]) best = i;
+    *theta = A[best][best];
+    for (int i = 0; i < k; ++i) u[i] = V[i][best];
+}
+
+__global__ void k_rr_solve(const double* __restrict__ partial, int nblk,
+                           const double* __restrict__ psum, int nscan, int use_mu, int n,
+                           Scalars* sc) {
+    if (sc->done) return;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double g[12];
+    for (int i = 0; i < 12; ++i) g[i] = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int i = 0; i < 12; ++i) g[i] += partial[b * 12 + i];
+    sc->mu = use_mu ? mean_from_psum(psum, nscan, n) : 0.0;
+    const double GB[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
+    const double GA[3][3] = {{g[6], g[7], g[8]}, {g[7], g[9], g[10]}, {g[8], g[10], g[11]}};
+    // active basis vectors: non-negligible norm relative to x
+    int idx[3];
+    int k = 0;
+    double s[3];
+    for (int i = 0; i < 3; ++i) {
+        if (GB[i][i] > 1e-280 && (i == 0 || GB[i][i] > 1e-60 * GB[0][0])) {
+            idx[k] = i;
+            s[k] = 1.0 / sqrt(GB[i][i]);
+            ++k;
+        }
+    }
+    double coef[3] = {0.0, 0.0, 0.0};
+    double theta = sc->theta;
+    if (k == 0 || idx[0] != 0) {  // x vanished: breakdown
+        sc->done = 2;
+        return;
+    }
+    while (k >= 1) {
+        double B[3][3], A[3][3];
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                B[i][j] = GB[idx[i]][idx[j]] * s[i] * s[j];
+                A[i][j] = GA[idx[i]][idx[j]] * s[i] * s[j];
+            }
+        // Cholesky B = Lc Lc^T with a pivot floor: near-dependent basis → drop the last vector
+        double Lc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        bool ok = true;
+        for (int j = 0; j < k && ok; ++j) {
+            double dsum = B[j][j];
+            for (int t = 0; t < j; ++t) dsum -= Lc[j][t] * Lc[j][t];
+            if (!(dsum > 1e-12)) {
+                ok = false;
+                break;
+            }
+            Lc[j][j] = sqrt(dsum);
+            for (int i = j + 1; i < k; ++i) {
+                double v = B[i][j];
+                for (int t = 0; t < j; ++t) v -= Lc[i][t] * Lc[j][t];
+                Lc[i][j] = v / Lc[j][j];
+            }
+        }
+        if (!ok) {
+            --k;
+            continue;
+        }
+        // C = Lc^-1 A Lc^-T
+        double T[3][3], C[3][3];
+        for (int c = 0; c < k; ++c) {  // solve Lc * T[:,c] = A[:,c]
+            for (int i = 0; i < k; ++i) {
+                double v = A[i][c];
+                for (int t = 0; t < i; ++t) v -= Lc[i][t] * T[t][c];
+                T[i][c] = v / Lc[i][i];
+            }
+        }
+        for (int r = 0; r < k; ++r) {  // C[r,:] : solve Lc * C[r,:]^T = T[r,:]^T
+            for (int i = 0; i < k; ++i) {
+                double v = T[r][i];
+                for (int t = 0; t < i; ++t) v -= Lc[i][t] * C[r][t];
+                C[r][i] = v / Lc[i][i];
+            }
+        }
+        for (int i = 0; i < k; ++i)
+            for (int j = i + 1; j < k; ++j) C[i][j] = C[j][i] = 0.5 * (C[i][j] + C[j][i]);
+        double u[3];
+        jacobi_smallest(k, C, &theta, u);
+        // c' = Lc^-T u
+        double cp[3];
+        for (int i = k - 1; i >= 0; --i) {
+            double v = u[i];
+            for (int t = i + 1; t < k; ++t) v -= Lc[t][i] * cp[t];
+            cp[i] = v / Lc[i][i];
+        }
+        for (int i = 0; i < k; ++i) coef[idx[i]] = cp[i] * s[i];
+        break;
+    }
+    if (coef[0] < 0.0) {  // keep the orientation of x
+        coef[0] = -coef[0];
+        coef[1] = -coef[1];
+        coef[2] = -coef[2];
+    }
+    sc->theta = theta;
+    sc->coef[0] = coef[0];
+    sc->coef[1] = coef[1];
+    sc->coef[2] = coef[2];
+}
+
+// x, p, Ax, Ap ← Ritz update;  r = Ax - theta x;  partial ||r||_1
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ x, const double* __restrict__ w,
+                                                double* __restrict__ p, double* __restrict__ Ax,
+                                                const double* __restrict__ Aw,
+                                                double* __restrict__ Ap, double* __restrict__ r,
+                                                int n, double* __restrict__ rpart, Scalars* sc) {
+    if (sc->done) return;
+    __shared__ double smem[4];
+    const double c0 = sc->coef[0], c1 = sc->coef[1], c2 = sc->coef[2];
+    const double mu = sc->mu, theta = sc->theta;
+    double v[1] = {0.0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double wi = w[i] - mu;
+        double pn = c1 * wi + c2 * p[i];
+        double apn = c1 * Aw[i] + c2 * Ap[i];
+        double xn = c0 * x[i] + pn;
+        double axn = c0 * Ax[i] + apn;
+        x[i] = xn;
+        p[i] = pn;
+        Ax[i] = axn;
+        Ap[i] = apn;
+        double ri = axn - theta * xn;
+        r[i] = ri;
+        v[0] += fabs(ri);
+    }
+    block_sum<1>(v, smem);
+    if (threadIdx.x == 0) rpart[blockIdx.x] = v[0];
+}
+
+__global__ void k_check(const double* __restrict__ rpart, int nblk, Scalars* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (sc->done) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += rpart[b];
+    double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
+    sc->lnorm = lnorm;
+    sc->res = s / lnorm;
+    sc->iters += 1;
+    if (sc->res < sc->tol)
+        sc->done = 1;
+    else if (sc->iters >= sc->max_iters)
+        sc->done = 3;
+    if (!(sc->res == sc->res)) sc->done = 2;  // NaN
+}
+
+// --------------------------------------------------------------------------------------------
+// Frank-Wolfe pieces (mac.py:112-130, :132-147, :191-233)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grad(const int32_t* __restrict__ ci,
+                                              const int32_t* __restrict__ cj,
+                                              const double* __restrict__ cw,
+                                              const double* __restrict__ v, int64_t m,
+                                              double* __restrict__ g) {
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    double d = v[ci[k]] - v[cj[k]];
+    double kdelta = cw[k] * d;  // mac.py:128
+    g[k] = kdelta * d;          // mac.py:129
+}
+
+__device__ inline unsigned long long d2ord(double x) {
+    if (x == 0.0) x = 0.0;
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return u ^ ((u >> 63) ? 0xFFFFFFFFFFFFFFFFull : 0x8000000000000000ull);
+}
+
+// mask of the k largest entries of x[0..m): radix select (8 x 8 bits) in one 1024-thread block;
+// among entries equal to the k-th value the lowest indices are kept.
+__global__ __launch_bounds__(1024) void k_topk_mask(const double* __restrict__ x, int64_t m,
+                                                    int64_t k, double* __restrict__ mask) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ long long s_krem;
+    __shared__ long long s_run;
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x;
+    if (k <= 0) {
+        for (int64_t i = tid; i < m; i += 1024) mask[i] = 0.0;
+        return;
+    }
+    if (k >= m) {
+        for (int64_t i = tid; i < m; i += 1024) mask[i] = 1.0;
+        return;
+    }
+    if (tid == 0) {
+        s_prefix = 0ull;
+        s_krem = k;
+    }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const int shift = pass * 8;
+        const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
+        for (int64_t i = tid; i < m; i += 1024) {
+            unsigned long long key = d2ord(x[i]);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long krem = s_krem;
+            int bin = 255;
+            for (; bin > 0; --bin) {
+                if ((long long)hist[bin] >= krem) break;
+                krem -= hist[bin];
+            }
+            s_krem = krem;
+            s_prefix = prefix | ((unsigned long long)bin << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long thr = s_prefix;
+    const long long need_eq = s_krem;  // how many entries == thr to keep (lowest index first)
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 1024) {
+        int64_t i = base + tid;
+        unsigned long long key = (i < m) ? d2ord(x[i]) : 0ull;
+        int eq = (i < m && key == thr) ? 1 : 0;
+        // exclusive scan of eq across the block
+        int lane = tid & 63, wv = tid >> 6;
+        int incl = eq;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int wofs = 0;
+        for (int q = 0; q < wv; ++q) wofs += wsum[q];
+        long long rank = s_run + wofs + incl - eq;
+        if (i < m) mask[i] = (key > thr || (eq && rank < need_eq)) ? 1.0 : 0.0;
+        __syncthreads();
+        if (tid == 1023) s_run += wofs + incl;
+        __syncthreads();
+    }
+}
+
+// u = min(u, f + g.(s - w)); gap test (mac.py:219-225)
+__global__ __launch_bounds__(1024) void k_fw_dual(const double* __restrict__ g,
+                                                  const double* __restrict__ s,
+                                                  const double* __restrict__ w, int64_t m,
+                                                  Scalars* sc) {
+    __shared__ double smem[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) acc += g[i] * (s[i] - w[i]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += smem[q];
+        double f = sc->theta;
+        double u = fmin(sc->fw_u, f + t);
+        sc->fw_f = f;
+        sc->fw_u = u;
+        sc->fw_done = (u - f < sc->fw_gap_tol) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fw_step(double* __restrict__ w,
+                                                 const double* __restrict__ s, int64_t m,
+                                                 const Scalars* sc) {
+    if (sc->fw_done) return;
+    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    double wk = w[k];
+    w[k] = wk + sc->fw_alpha * (s[k] - wk);  // mac.py:229-230
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct cslam_mac {
+    int device = 0;
+    int n = 0;
+    int64_t nf = 0, m = 0;
+    std::vector<int32_t> fi, fj, ci, cj;
+    std::vector<double> fw, cw;
+    bool fixed_connected = false;
+    hipStream_t stream = nullptr;
+    // device
+    int32_t *adj_ptr = nullptr, *adj_nbr = nullptr, *adj_eid = nullptr;
+    int32_t *ci_d = nullptr, *cj_d = nullptr;
+    double *cw_d = nullptr, *ew = nullptr;
+    uint8_t* link = nullptr;
+    int32_t *seg_start = nullptr, *seg_len = nullptr;
+    int nseg = 0;
+    double *a = nullptr, *b = nullptr, *l = nullptr, *invd = nullptr;
+    double *x = nullptr, *w = nullptr, *p = nullptr, *Ax = nullptr, *Aw = nullptr, *Ap = nullptr,
+           *r = nullptr, *y = nullptr;
+    Aff *agg_f = nullptr, *agg_b = nullptr;
+    double *psum = nullptr, *partial = nullptr, *rpart = nullptr;
+    Scalars* sc = nullptr;
+    double *wvec = nullptr, *gvec = nullptr, *svec = nullptr;  // FW state [m]
+    int nscan = 0, nred = 0;
+    bool have_warm = false;
+    hipGraphExec_t graph = nullptr;
+    // stats
+    int64_t spmv_count = 0;
+    double device_ms = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    CSLAM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (count > 0 ? count : 1) * sizeof(T)));
+    return CSLAM_OK;
+}
+
+struct UnionFind {
+    std::vector<int32_t> parent;
+    explicit UnionFind(int n) : parent(n) { std::iota(parent.begin(), parent.end(), 0); }
+    int find(int v) {
+        while (parent[v] != v) {
+            parent[v] = parent[parent[v]];
+            v = parent[v];
+        }
+        return v;
+    }
+    bool unite(int a, int b) {
+        a = find(a);
+        b = find(b);
+        if (a == b) return false;
+        parent[a] = b;
+        return true;
+    }
+};
+
+// connected iff n-1 successful unions
+bool graph_connected(const cslam_mac* mac, const double* w, double tol) {
+    if (mac->n <= 1) return true;
+    UnionFind uf(mac->n);
+    int64_t comps = mac->n;
+    for (int64_t e = 0; e < mac->nf; ++e)
+        if (mac->fw[e] != 0.0 && uf.unite(mac->fi[e], mac->fj[e])) --comps;
+    if (w)
+        for (int64_t k = 0; k < mac->m && comps > 1; ++k)
+            if (w[k] > tol && w[k] * mac->cw[k] != 0.0 && uf.unite(mac->ci[k], mac->cj[k])) --comps;
+    return comps == 1;
+}
+
+void launch_iteration(cslam_mac* mac, hipStream_t st) {
+    const int n = mac->n;
+    const unsigned gs = (unsigned)mac->nscan, gr = (unsigned)mac->nred;
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    // w = M^-1 r  (forward + backward affine scans), psum = per-block sums of w
+    hipLaunchKernelGGL((k_scan_agg<0>), dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
+                       mac->invd, n, mac->agg_f, mac->sc);
+    hipLaunchKernelGGL((k_scan_apply<0>), dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
+                       mac->invd, n, mac->agg_f, mac->y, mac->psum, mac->sc);
+    hipLaunchKernelGGL((k_scan_agg<1>), dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l,
+                       mac->invd, n, mac->agg_b, mac->sc);
+    hipLaunchKernelGGL((k_scan_apply<1>), dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l,
+                       mac->invd, n, mac->agg_b, mac->w, mac->psum, mac->sc);
+    // Aw = L w
+    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr,
+                       mac->adj_eid, mac->ew, mac->w, mac->Aw, n, mac->sc);
+    hipLaunchKernelGGL(k_dots, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax, mac->Aw,
+                       mac->Ap, n, mac->psum, mac->nscan, 1, mac->partial, mac->sc);
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(64), 0, st, mac->partial, mac->nred, mac->psum,
+                       mac->nscan, 1, n, mac->sc);
+    hipLaunchKernelGGL(k_update, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax,
+                       mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, mac->rpart, mac->nred, mac->sc);
+}
+
+int build_graph(cslam_mac* mac) {
+    if (mac->graph) return CSLAM_OK;
+    hipGraph_t g = nullptr;
+    CSLAM_HIP_TRY(hipStreamBeginCapture(mac->stream, hipStreamCaptureModeThreadLocal));
+    for (int it = 0; it < kIterPerGraph; ++it) launch_iteration(mac, mac->stream);
+    CSLAM_HIP_TRY(hipStreamEndCapture(mac->stream, &g));
+    CSLAM_HIP_TRY(hipGraphInstantiate(&mac->graph, g, nullptr, nullptr, 0));
+    CSLAM_HIP_TRY(hipGraphDestroy(g));
+    return CSLAM_OK;
+}
+
+// Fiedler pair of L(w) with w already on the device in mac->wvec.  Leaves theta in sc, v in x.
+int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
+    const int n = mac->n;
+    hipStream_t st = mac->stream;
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    if (mac->m > 0) {
+        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((mac->m + 255) / 256)), dim3(256), 0, st,
+                           mac->wvec, mac->cw_d, mac->m, 1e-10, mac->ew + mac->nf);
+    }
+    Scalars init;
+    std::memset(&init, 0, sizeof(init));
+    // Converge tighter than the reference's tol (networkx stops at res < tol = 1e-8 with an
+    // eigenvector error of ~1e-6): the Ritz value error is O(res^2), the vector error O(res).
+    init.tol = tol_abi * 1e-2;
+    init.max_iters = kMaxIters;
+    Scalars keep;
+    CSLAM_HIP_TRY(hipMemcpyAsync(&keep, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    init.fw_f = keep.fw_f;
+    init.fw_u = keep.fw_u;
+    init.fw_gap_tol = keep.fw_gap_tol;
+    init.fw_alpha = keep.fw_alpha;
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_diag, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->adj_eid,
+                       mac->ew, mac->link, n, mac->a, mac->b, mac->sc);
+    hipLaunchKernelGGL(k_factor, dim3((unsigned)((mac->nseg + 63) / 64)), dim3(64), 0, st,
+                       mac->seg_start, mac->seg_len, mac->nseg, mac->a, mac->b, mac->l, mac->invd,
+                       mac->sc);
+    // bootstrap: Ax = L x, 1x1 Rayleigh-Ritz (w = p = 0), r = Ax - theta x
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
+    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr,
+                       mac->adj_eid, mac->ew, mac->x, mac->Ax, n, mac->sc);
+    hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
+                       mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(64), 0, st, mac->partial, mac->nred, mac->psum,
+                       mac->nscan, 0, n, mac->sc);
+    hipLaunchKernelGGL(k_update, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
+                       mac->Ax, mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, mac->rpart, mac->nred, mac->sc);
+    CSLAM_HIP_TRY(hipGetLastError());
+    CSLAM_TRY(build_graph(mac));
+    Scalars h;
+    int replays = 0;
+    while (true) {
+        CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        if (h.factor_bad)
+            return fail(CSLAM_E_DISCONNECTED,
+                        "tridiagonal pivot <= 0: L(w) has an isolated node (disconnected graph)");
+        if (h.done) break;
+        CSLAM_HIP_TRY(hipGraphLaunch(mac->graph, st));
+        ++replays;
+    }
+    mac->spmv_count += h.iters;
+    if (iters_out) *iters_out = h.iters;
+    if (h.done == 2) return fail(CSLAM_E_NOCONV, "LOBPCG breakdown (NaN / vanished basis)");
+    if (h.done == 3)
+        return fail(CSLAM_E_NOCONV, "LOBPCG did not reach res < %.3g in %d iterations (res %.3g)",
+                    init.tol, h.iters, h.res);
+    // a (numerically) zero Fiedler value means the graph is disconnected
+    if (!(h.theta > 1e-13 * h.lnorm))
+        return fail(CSLAM_E_DISCONNECTED, "lambda_2 = %.3g ~ 0: disconnected graph", h.theta);
+    mac->have_warm = true;
+    return CSLAM_OK;
+}
+
+void cold_start_vector(int n, std::vector<double>& v) {
+    // deterministic pseudo-random start, centred and normalised (any vector with a component
+    // along v_2 works; the reference draws RandomState(7).normal, mac.py:58)
+    v.resize(n);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    double mean = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        v[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+        mean += v[i];
+    }
+    mean /= n;
+    double nn = 0.0;
+    for (int i = 0; i < n; ++i) {
+        v[i] -= mean;
+        nn += v[i] * v[i];
+    }
+    nn = nn > 0 ? 1.0 / std::sqrt(nn) : 1.0;
+    for (int i = 0; i < n; ++i) v[i] *= nn;
+}
+
+int upload_w_and_check(cslam_mac* mac, const double* w, double tol) {
+    if (!mac->fixed_connected && !graph_connected(mac, w, tol))
+        return fail(CSLAM_E_DISCONNECTED,
+                    "L(w) is the Laplacian of a disconnected graph (reference: SuperLU "
+                    "'Factor is exactly singular')");
+    if (mac->m > 0)
+        CSLAM_HIP_TRY(hipMemcpyAsync(mac->wvec, w, sizeof(double) * mac->m, hipMemcpyHostToDevice,
+                                     mac->stream));
+    return CSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* fixed_j,
+                     const double* fixed_w, int64_t n_fixed, const int32_t* cand_i,
+                     const int32_t* cand_j, const double* cand_w, int64_t n_cand, int device_id,
+                     cslam_mac_t** out) {
+    if (!out || num_poses <= 0 || n_fixed < 0 || n_cand < 0 ||
+        (n_fixed > 0 && (!fixed_i || !fixed_j || !fixed_w)) ||
+        (n_cand > 0 && (!cand_i || !cand_j || !cand_w)))
+        return fail(CSLAM_E_INVALID, "mac_create: bad args");
+    for (int64_t e = 0; e < n_fixed; ++e)
+        if (fixed_i[e] < 0 || fixed_i[e] >= num_poses || fixed_j[e] < 0 || fixed_j[e] >= num_poses)
+            return fail(CSLAM_E_INVALID, "mac_create: fixed edge %lld out of range", (long long)e);
+    for (int64_t e = 0; e < n_cand; ++e)
+        if (cand_i[e] < 0 || cand_i[e] >= num_poses || cand_j[e] < 0 || cand_j[e] >= num_poses)
+            return fail(CSLAM_E_INVALID, "mac_create: candidate edge %lld out of range", (long long)e);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CSLAM_E_NODEVICE, "mac_create: no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return fail(CSLAM_E_INVALID, "mac_create: bad device");
+    CSLAM_HIP_TRY(hipSetDevice(device_id));
+
+    cslam_mac* mac = new cslam_mac();
+    mac->device = device_id;
+    mac->n = num_poses;
+    mac->nf = n_fixed;
+    mac->m = n_cand;
+    mac->fi.assign(fixed_i, fixed_i + n_fixed);
+    mac->fj.assign(fixed_j, fixed_j + n_fixed);
+    mac->fw.assign(fixed_w, fixed_w + n_fixed);
+    mac->ci.assign(cand_i, cand_i + n_cand);
+    mac->cj.assign(cand_j, cand_j + n_cand);
+    mac->cw.assign(cand_w, cand_w + n_cand);
+    mac->fixed_connected = graph_connected(mac, nullptr, 0.0);
+
+    const int n = mac->n;
+    const int64_t E = n_fixed + n_cand;
+    // edge adjacency (self loops contribute nothing to a Laplacian: skipped)
+    std::vector<int32_t> ptr(n + 1, 0);
+    auto each_edge = [&](auto&& fn) {
+        for (int64_t e = 0; e < n_fixed; ++e) fn(e, fixed_i[e], fixed_j[e]);
+        for (int64_t e = 0; e < n_cand; ++e) fn(n_fixed + e, cand_i[e], cand_j[e]);
+    };
+    each_edge([&](int64_t, int i, int j) {
+        if (i != j) {
+            ptr[i + 1]++;
+            ptr[j + 1]++;
+        }
+    });
+    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    std::vector<int32_t> nbr(ptr[n]), eid(ptr[n]), fill(ptr.begin(), ptr.end() - 1);
+    each_edge([&](int64_t e, int i, int j) {
+        if (i != j) {
+            nbr[fill[i]] = j;
+            eid[fill[i]++] = (int32_t)e;
+            nbr[fill[j]] = i;
+            eid[fill[j]++] = (int32_t)e;
+        }
+    });
+    // chain links: fixed edges between consecutive node ids
+    std::vector<uint8_t> link(n, 0);
+    for (int64_t e = 0; e < n_fixed; ++e) {
+        int i = fixed_i[e], j = fixed_j[e];
+        if (std::abs(i - j) == 1 && fixed_w[e] > 0.0) link[std::min(i, j)] = 1;
+    }
+    std::vector<int32_t> seg_start, seg_len;
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j + 1 < n && link[j]) ++j;
+        seg_start.push_back(i);
+        seg_len.push_back(j - i + 1);
+        i = j + 1;
+    }
+    mac->nseg = (int)seg_start.size();
+    mac->nscan = (n + kScanBlock - 1) / kScanBlock;
+    mac->nred = std::min(kRedBlocksMax, (n + 255) / 256);
+
+    int rc = CSLAM_OK;
+    auto A = [&](int r) {
+        if (rc == CSLAM_OK) rc = r;
+    };
+    hipError_t se = hipStreamCreateWithFlags(&mac->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete mac;
+        return fail(CSLAM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+    }
+    A(dev_alloc(&mac->adj_ptr, n + 1));
+    A(dev_alloc(&mac->adj_nbr, nbr.size()));
+    A(dev_alloc(&mac->adj_eid, eid.size()));
+    A(dev_alloc(&mac->ci_d, n_cand));
+    A(dev_alloc(&mac->cj_d, n_cand));
+    A(dev_alloc(&mac->cw_d, n_cand));
+    A(dev_alloc(&mac->ew, E));
+    A(dev_alloc(&mac->link, n));
+    A(dev_alloc(&mac->seg_start, seg_start.size()));
+    A(dev_alloc(&mac->seg_len, seg_len.size()));
+    for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
+                       &mac->Aw, &mac->Ap, &mac->r, &mac->y})
+        A(dev_alloc(v, n));
+    A(dev_alloc(&mac->agg_f, mac->nscan));
+    A(dev_alloc(&mac->agg_b, mac->nscan));
+    A(dev_alloc(&mac->psum, mac->nscan));
+    A(dev_alloc(&mac->partial, (size_t)mac->nred * 12));
+    A(dev_alloc(&mac->rpart, mac->nred));
+    A(dev_alloc(&mac->sc, 1));
+    A(dev_alloc(&mac->wvec, n_cand));
+    A(dev_alloc(&mac->gvec, n_cand));
+    A(dev_alloc(&mac->svec, n_cand));
+    if (rc != CSLAM_OK) {
+        cslam_mac_destroy(mac);
+        return rc;
+    }
+    auto H2D = [&](void* d, const void* h, size_t bytes) {
+        if (rc == CSLAM_OK && bytes > 0 && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(CSLAM_E_HIP, "mac_create: H2D copy failed");
+    };
+    H2D(mac->adj_ptr, ptr.data(), ptr.size() * 4);
+    H2D(mac->adj_nbr, nbr.data(), nbr.size() * 4);
+    H2D(mac->adj_eid, eid.data(), eid.size() * 4);
+    H2D(mac->ci_d, cand_i, n_cand * 4);
+    H2D(mac->cj_d, cand_j, n_cand * 4);
+    H2D(mac->cw_d, cand_w, n_cand * 8);
+    H2D(mac->ew, fixed_w, n_fixed * 8);
+    H2D(mac->link, link.data(), n);
+    H2D(mac->seg_start, seg_start.data(), seg_start.size() * 4);
+    H2D(mac->seg_len, seg_len.data(), seg_len.size() * 4);
+    std::vector<double> x0;
+    cold_start_vector(n, x0);
+    H2D(mac->x, x0.data(), (size_t)n * 8);
+    if (rc == CSLAM_OK && (hipMemset(mac->sc, 0, sizeof(Scalars)) != hipSuccess ||
+                           hipMemset(mac->l, 0, sizeof(double) * n) != hipSuccess ||
+                           hipMemset(mac->b, 0, sizeof(double) * n) != hipSuccess ||
+                           hipEventCreate(&mac->ev0) != hipSuccess ||
+                           hipEventCreate(&mac->ev1) != hipSuccess))
+        rc = fail(CSLAM_E_HIP, "mac_create: init failed");
+    if (rc != CSLAM_OK) {
+        cslam_mac_destroy(mac);
+        return rc;
+    }
+    *out = mac;
+    return CSLAM_OK;
+}
+
+int cslam_mac_destroy(cslam_mac_t* mac) {
+    if (!mac) return CSLAM_OK;
+    (void)hipSetDevice(mac->device);
+    if (mac->stream) (void)hipStreamSynchronize(mac->stream);
+    if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
+    for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
+                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->link,
+                    (void*)mac->seg_start, (void*)mac->seg_len, (void*)mac->a, (void*)mac->b,
+                    (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
+                    (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
+                    (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->psum, (void*)mac->partial,
+                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->wvec, (void*)mac->gvec,
+                    (void*)mac->svec})
+        if (p) (void)hipFree(p);
+    if (mac->ev0) (void)hipEventDestroy(mac->ev0);
+    if (mac->ev1) (void)hipEventDestroy(mac->ev1);
+    if (mac->stream) (void)hipStreamDestroy(mac->stream);
+    delete mac;
+    return CSLAM_OK;
+}
+
+// combined_laplacian(w) as CSR with duplicates summed and column indices sorted
+// (introspection / parity API; the solver itself works on the edge adjacency).
+int cslam_mac_laplacian(cslam_mac_t* mac, const double* w, double tol, int64_t* nnz,
+                        int32_t* indptr, int32_t* indices, double* data) {
+    if (!mac || !nnz || (mac->m > 0 && !w)) return fail(CSLAM_E_INVALID, "mac_laplacian: bad args");
+    const int n = mac->n;
+    struct Trip {
+        int32_t r, c;
+        double v;
+    };
+    std::vector<Trip> t;
+    t.reserve(4 * (size_t)(mac->nf + mac->m));
+    auto push = [&](int i, int j, double v) {
+        t.push_back({i, i, v});
+        t.push_back({j, j, v});
+        t.push_back({i, j, -v});
+        t.push_back({j, i, -v});
+    };
+    for (int64_t e = 0; e < mac->nf; ++e) push(mac->fi[e], mac->fj[e], mac->fw[e]);
+    // L_odom + C1: both are duplicate-summed CSRs added together (mac.py:76); the sum of sums
+    // is order-insensitive up to rounding, which the parity test allows for (1 ulp).
+    for (int64_t k = 0; k < mac->m; ++k)
+        if (w[k] > tol) push(mac->ci[k], mac->cj[k], w[k] * mac->cw[k]);
+    std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) {
+        return a.r != b.r ? a.r < b.r : a.c < b.c;
+    });
+    std::vector<int32_t> ptr(n + 1, 0), idx;
+    std::vector<double> val;
+    for (size_t q = 0; q < t.size();) {
+        size_t e = q;
+        double s = 0.0;
+        while (e < t.size() && t[e].r == t[q].r && t[e].c == t[q].c) s += t[e++].v;
+        idx.push_back(t[q].c);
+        val.push_back(s);
+        ptr[t[q].r + 1]++;
+        q = e;
+    }
+    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    if (indptr && indices && data) {
+        if (*nnz < (int64_t)idx.size())
+            return fail(CSLAM_E_INVALID, "mac_laplacian: buffer too small (%lld < %zu)",
+                        (long long)*nnz, idx.size());
+        std::memcpy(indptr, ptr.data(), ptr.size() * 4);
+        std::memcpy(indices, idx.data(), idx.size() * 4);
+        std::memcpy(data, val.data(), val.size() * 8);
+    }
+    *nnz = (int64_t)idx.size();
+    return CSLAM_OK;
+}
+
+int cslam_mac_fiedler(cslam_mac_t* mac, const double* w, double tol, double* lambda2, double* v,
+                      int32_t* iters) {
+    if (!mac || !lambda2 || (mac->m > 0 && !w) || !(tol > 0))
+        return fail(CSLAM_E_INVALID, "mac_fiedler: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(mac->device));
+    CSLAM_TRY(upload_w_and_check(mac, w, 1e-10));
+    CSLAM_HIP_TRY(hipEventRecord(mac->ev0, mac->stream));
+    int rc = fiedler_device(mac, tol, iters);
+    if (rc != CSLAM_OK) {
+        // a failed solve must not poison the next one's warm start
+        std::vector<double> x0;
+        cold_start_vector(mac->n, x0);
+        (void)hipMemcpy(mac->x, x0.data(), (size_t)mac->n * 8, hipMemcpyHostToDevice);
+        mac->have_warm = false;
+        return rc;
+    }
+    CSLAM_HIP_TRY(hipEventRecord(mac->ev1, mac->stream));
+    Scalars h;
+    CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, mac->stream));
+    std::vector<double> hv(mac->n);
+    CSLAM_HIP_TRY(hipMemcpyAsync(hv.data(), mac->x, (size_t)mac->n * 8, hipMemcpyDeviceToHost,
+                                 mac->stream));
+    CSLAM_HIP_TRY(hipStreamSynchronize(mac->stream));
+    float ms = 0.f;
+    CSLAM_HIP_TRY(hipEventElapsedTime(&ms, mac->ev0, mac->ev1));
+    mac->device_ms = ms;
+    *lambda2 = h.theta;
+    if (v) {
+        // unit norm, sign: entry of largest magnitude (first on ties) positive
+        double nn = 0.0;
+        size_t big = 0;
+        for (size_t i = 0; i < hv.size(); ++i) {
+            nn += hv[i] * hv[i];
+            if (std::fabs(hv[i]) > std::fabs(hv[big])) big = i;
+        }
+        double sgn = (hv[big] < 0 ? -1.0 : 1.0) / std::sqrt(nn);
+        for (size_t i = 0; i < hv.size(); ++i) v[i] = hv[i] * sgn;
+    }
+    return CSLAM_OK;
+}
+
+int cslam_mac_grad(cslam_mac_t* mac, const double* v, double* g) {
+    if (!mac || !v || (mac->m > 0 && !g)) return fail(CSLAM_E_INVALID, "mac_grad: bad args");
+    if (mac->m == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(mac->device));
+    hipStream_t st = mac->stream;
+    // y is scratch outside a solve
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->y, v, (size_t)mac->n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_grad, dim3((unsigned)((mac->m + 255) / 256)), dim3(256), 0, st, mac->ci_d,
+                       mac->cj_d, mac->cw_d, mac->y, mac->m, mac->gvec);
+    CSLAM_HIP_TRY(hipGetLastError());
+    CSLAM_HIP_TRY(hipMemcpyAsync(g, mac->gvec, (size_t)mac->m * 8, hipMemcpyDeviceToHost, st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    return CSLAM_OK;
+}
+
+int cslam_topk_mask(const double* x, int64_t m, int64_t k, double* mask) {
+    if (m < 0 || k < 0 || (m > 0 && (!x || !mask))) return fail(CSLAM_E_INVALID, "topk_mask: bad args");
+    if (m == 0) return CSLAM_OK;
+    double *dx = nullptr, *dm = nullptr;
+    CSLAM_HIP_TRY(hipMalloc(&dx, m * 8));
+    hipError_t e = hipMalloc(&dm, m * 8);
+    if (e != hipSuccess) {
+        (void)hipFree(dx);
+        return fail(CSLAM_E_HIP, "topk_mask: hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = CSLAM_OK;
+    if (hipMemcpy(dx, x, m * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(CSLAM_E_HIP, "topk_mask: H2D failed");
+    if (rc == CSLAM_OK) {
+        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, 0, dx, m, k, dm);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(mask, dm, m * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(CSLAM_E_HIP, "topk_mask: kernel/D2H failed");
+    }
+    (void)hipFree(dx);
+    (void)hipFree(dm);
+    return rc;
+}
+
+// round_solution_tiebreaker (mac.py:168-189): k largest under the lexicographic key
+// (np.round(w, decimals), weight).  Runs once per fw_subset on a relaxed solution already on
+// the host; ties beyond the key are broken by lowest index.
+int cslam_mac_round_tiebreak(cslam_mac_t* mac, const double* w, int64_t k, int decimals,
+                             double* mask) {
+    if (!mac || (mac->m > 0 && (!w || !mask)) || k < 0)
+        return fail(CSLAM_E_INVALID, "mac_round_tiebreak: bad args");
+    const int64_t m = mac->m;
+    const double scale = std::pow(10.0, decimals);
+    std::vector<double> tw(m);
+    for (int64_t i = 0; i < m; ++i) tw[i] = std::nearbyint(w[i] * scale) / scale;  // np.round
+    std::vector<int64_t> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    const int64_t kk = std::min(k, m);
+    auto better = [&](int64_t a, int64_t b) {
+        if (tw[a] != tw[b]) return tw[a] > tw[b];
+        if (mac->cw[a] != mac->cw[b]) return mac->cw[a] > mac->cw[b];
+        return a < b;
+    };
+    if (kk > 0 && kk < m) std::nth_element(order.begin(), order.begin() + (kk - 1), order.end(), better);
+    for (int64_t i = 0; i < m; ++i) mask[i] = 0.0;
+    for (int64_t i = 0; i < kk; ++i) mask[order[i]] = 1.0;
+    return CSLAM_OK;
+}
+
+int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int max_iters,
+                        double duality_gap_tol, double* w_round, double* w_relaxed, double* upper,
+                        int32_t* iters_done, double* lambda_trace) {
+    if (!mac || mac->m <= 0 || !w_init || k < 0 || max_iters < 0 || !w_round || !w_relaxed || !upper)
+        return fail(CSLAM_E_INVALID, "mac_fw_subset: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(mac->device));
+    hipStream_t st = mac->stream;
+    const int64_t m = mac->m;
+    const unsigned gm = (unsigned)((m + 255) / 256);
+    std::vector<double> hw(w_init, w_init + m);
+    Scalars h;
+    std::memset(&h, 0, sizeof(h));
+    h.fw_u = INFINITY;
+    h.fw_gap_tol = duality_gap_tol;
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &h, sizeof(Scalars), hipMemcpyHostToDevice, st));
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->wvec, hw.data(), m * 8, hipMemcpyHostToDevice, st));
+    CSLAM_HIP_TRY(hipEventRecord(mac->ev0, st));
+    int it = 0;
+    double u = INFINITY;
+    bool stopped = false;
+    for (; it < max_iters; ++it) {
+        if (!mac->fixed_connected) {
+            // rare path (fixed graph alone is not connected): the support of w decides
+            CSLAM_HIP_TRY(hipMemcpyAsync(hw.data(), mac->wvec, m * 8, hipMemcpyDeviceToHost, st));
+            CSLAM_HIP_TRY(hipStreamSynchronize(st));
+            if (!graph_connected(mac, hw.data(), 1e-10))
+                return fail(CSLAM_E_DISCONNECTED, "fw_subset: L(w) disconnected at iteration %d", it);
+        }
+        // keep the FW scalars across the solver's reset
+        const double alpha = 2.0 / (it + 2.0);
+        CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->fw_alpha, &alpha, 8, hipMemcpyHostToDevice, st));
+        int32_t its = 0;
+        int rc = fiedler_device(mac, 1e-8, &its);
+        if (rc != CSLAM_OK) {
+            std::vector<double> x0;
+            cold_start_vector(mac->n, x0);
+            (void)hipMemcpy(mac->x, x0.data(), (size_t)mac->n * 8, hipMemcpyHostToDevice);
+            mac->have_warm = false;
+            return rc;
+        }
+        hipLaunchKernelGGL(k_grad, dim3(gm), dim3(256), 0, st, mac->ci_d, mac->cj_d, mac->cw_d,
+                           mac->x, m, mac->gvec);
+        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, st, mac->gvec, m, k, mac->svec);
+        hipLaunchKernelGGL(k_fw_dual, dim3(1), dim3(1024), 0, st, mac->gvec, mac->svec, mac->wvec, m,
+                           mac->sc);
+        hipLaunchKernelGGL(k_fw_step, dim3(gm), dim3(256), 0, st, mac->wvec, mac->svec, m, mac->sc);
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        if (lambda_trace) lambda_trace[it] = h.fw_f;
+        u = h.fw_u;
+        if (h.fw_done) {  // "Duality gap tolerance reached" (mac.py:223-225): w is NOT stepped
+            ++it;
+            stopped = true;
+            break;
+        }
+    }
+    (void)stopped;
+    CSLAM_HIP_TRY(hipEventRecord(mac->ev1, st));
+    CSLAM_HIP_TRY(hipMemcpyAsync(w_relaxed, mac->wvec, m * 8, hipMemcpyDeviceToHost, st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    CSLAM_HIP_TRY(hipEventElapsedTime(&ms, mac->ev0, mac->ev1));
+    mac->device_ms = ms;
+    *upper = u;
+    if (iters_done) *iters_done = it;
+    return cslam_mac_round_tiebreak(mac, w_relaxed, k, 10, w_round);
+}
+
+int cslam_mac_stats(const cslam_mac_t* mac, int64_t* spmv_count, double* device_ms) {
+    if (!mac) return fail(CSLAM_E_INVALID, "mac_stats: bad args");
+    if (spmv_count) *spmv_count = mac->spmv_count;
+    if (device_ms) *device_ms = mac->device_ms;
+    return CSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""MAC — maximise algebraic connectivity; host mirror of cslam/mac/mac.py:19-233.
+
+Same class name, constructor and methods as the reference.  The numerics run on the GPU through
+the C ABI (include/cslam_hip.h, csrc/mac.hip): edge weights, L(w) mat-vec, the Fiedler pair
+(LOBPCG with a chain-tridiagonal preconditioner instead of networkx TraceMIN + SuperLU), the
+gradient, the top-k direction and the whole Frank-Wolfe loop.  There is no CPU fallback.
+
+Error behaviour kept from the reference: a disconnected L(w) raises (the reference's SuperLU
+raises RuntimeError('Factor is exactly singular'); here `GraphDisconnectedError`, also a
+RuntimeError) so the retry ladder of
+cslam/algebraic_connectivity_maximization.py:449-465 behaves the same.
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+
+from .. import _lib
+from .utils import Edge, weight_graph_lap_from_edge_list  # noqa: F401  (re-exported like mac.py:14)
+
+MACResult = namedtuple("MACResult", ["w", "F_unrounded", "objective_values", "duality_gaps"])
+
+
+class MAC:
+
+    def __init__(self, fixed_measurements, candidate_measurements, num_poses, device_id=0):
+        self._lib = _lib.load()
+        if self._lib.cslam_device_count() <= 0:
+            raise _lib.CslamHipError(_lib.CSLAM_E_NODEVICE,
+                                     "no HIP device visible; cslam_amd has no CPU path")
+        self.num_poses = int(num_poses)
+        self._fi = _lib.as_i32([e.i for e in fixed_measurements])
+        self._fj = _lib.as_i32([e.j for e in fixed_measurements])
+        self._fw = _lib.as_f64([e.weight for e in fixed_measurements])
+        self.weights = _lib.as_f64([e.weight for e in candidate_measurements])
+        self.edge_list = np.array([(e.i, e.j) for e in candidate_measurements],
+                                  dtype=np.int64).reshape(-1, 2)
+        self._ci = _lib.as_i32(self.edge_list[:, 0])
+        self._cj = _lib.as_i32(self.edge_list[:, 1])
+        self._handle = ctypes.c_void_p()
+        _lib.check(self._lib.cslam_mac_create(
+            self.num_poses, _lib.ptr(self._fi), _lib.ptr(self._fj), _lib.ptr(self._fw),
+            len(self._fw), _lib.ptr(self._ci), _lib.ptr(self._cj), _lib.ptr(self.weights),
+            len(self.weights), int(device_id), ctypes.byref(self._handle)))
+        self._L_odom = None
+        self.last_iters = 0
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.cslam_mac_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def L_odom(self):
+        """Laplacian of the fixed edges (mac.py:22), as scipy CSR."""
+        if self._L_odom is None:
+            self._L_odom = self.combined_laplacian(np.zeros(len(self.weights)))
+        return self._L_odom
+
+    # ---- L(w) ------------------------------------------------------------------------------
+    def combined_laplacian(self, w, tol=1e-10):
+        """L(w) = L_fixed + sum_k w_k c_k L_k over w_k > tol (mac.py:61-77), scipy CSR."""
+        from scipy.sparse import csr_matrix
+        w = _lib.as_f64(w)
+        nnz = ctypes.c_int64(0)
+        _lib.check(self._lib.cslam_mac_laplacian(self._handle, _lib.ptr(w), float(tol),
+                                                 ctypes.byref(nnz), None, None, None))
+        indptr = np.empty(self.num_poses + 1, np.int32)
+        indices = np.empty(max(nnz.value, 1), np.int32)
+        data = np.empty(max(nnz.value, 1), np.float64)
+        _lib.check(self._lib.cslam_mac_laplacian(self._handle, _lib.ptr(w), float(tol),
+                                                 ctypes.byref(nnz), _lib.ptr(indptr),
+                                                 _lib.ptr(indices), _lib.ptr(data)))
+        return csr_matrix((data[:nnz.value], indices[:nnz.value], indptr),
+                          shape=(self.num_poses, self.num_poses))
+
+    # ---- Fiedler pair ----------------------------------------------------------------------
+    def evaluate_fiedler_pair(self, w, method="tracemin_lu", tol=1e-8):
+        """(lambda_2(L(w)), v_2(L(w))) — mac.py:79-96.  `method` is accepted for signature
+        compatibility; the device solver is always used."""
+        w = _lib.as_f64(w)
+        if len(w) != len(self.weights):
+            raise ValueError("w has the wrong length")
+        lam = ctypes.c_double()
+        v = np.empty(self.num_poses, np.float64)
+        it = ctypes.c_int32()
+        _lib.check(self._lib.cslam_mac_fiedler(self._handle, _lib.ptr(w), float(tol),
+                                               ctypes.byref(lam), _lib.ptr(v), ctypes.byref(it)))
+        self.last_iters = it.value
+        return lam.value, v
+
+    def find_fiedler_pair(self, L, method="tracemin_lu", tol=1e-8):
+        """Fiedler pair of an arbitrary graph Laplacian given as a scipy sparse matrix
+        (mac.py:35-59).  The off-diagonal entries define the edges."""
+        assert method != "lobpcg"  # mac.py:51
+        from scipy.sparse import triu
+        U = triu(L, k=1).tocoo()
+        edges = [Edge(int(i), int(j), float(-v)) for i, j, v in zip(U.row, U.col, U.data) if v != 0]
+        tmp = MAC(edges, [], L.shape[0])
+        try:
+            return tmp.evaluate_fiedler_pair(np.zeros(0), method, tol)
+        finally:
+            tmp.close()
+
+    def evaluate_objective(self, w):
+        """F(w) = lambda_2(L(w)) (mac.py:98-110)."""
+        return self.evaluate_fiedler_pair(w)[0]
+
+    # ---- gradient and rounding -------------------------------------------------------------
+    def grad_from_fiedler(self, fiedler_vec):
+        """grad_k = weight_k (v_i - v_j)^2 (mac.py:112-130)."""
+        v = _lib.as_f64(fiedler_vec)
+        g = np.empty(len(self.weights), np.float64)
+        _lib.check(self._lib.cslam_mac_grad(self._handle, _lib.ptr(v), _lib.ptr(g)))
+        return g
+
+    def round_solution(self, w, k):
+        """0/1 vector of the k largest entries (mac.py:132-147); ties → lowest index."""
+        w = _lib.as_f64(w)
+        out = np.zeros(len(w), np.float64)
+        if k > 0 and len(w) > 0:
+            _lib.check(self._lib.cslam_topk_mask(_lib.ptr(w), len(w), int(k), _lib.ptr(out)))
+        return out
+
+    def round_solution_tiebreaker(self, w, k, decimal_tol=10):
+        """k largest by (round(w, decimal_tol), weight) (mac.py:168-189).
+
+        Evaluated with the very numpy call the reference makes so that exact ties (equal
+        rounded w AND equal weight — common when all candidate weights are 1) resolve to the
+        same edges as the reference; the structured array is built vectorised instead of by
+        a Python loop."""
+        w = np.asarray(w, dtype=np.float64)
+        keys = np.empty(len(w), dtype=[("w", "float"), ("weight", "float")])
+        keys["w"] = w.round(decimals=decimal_tol)
+        keys["weight"] = self.weights
+        rounded = np.zeros(len(w))
+        if k > 0:
+            rounded[np.argpartition(keys, -k, order=["w", "weight"])[-k:]] = 1.0
+        return rounded
+
+    def simple_random_round(self, w, k):
+        """Bernoulli rounding (mac.py:149-166)."""
+        return (np.asarray(w) > np.random.rand(len(w))).astype(np.float64)
+
+    # ---- Frank-Wolfe -----------------------------------------------------------------------
+    def fw_subset(self, w_init, k, max_iters=5, duality_gap_tol=1e-8):
+        """Frank-Wolfe on the relaxed subset-selection problem (mac.py:191-233), whole loop on
+        the device.  Returns (rounded, unrounded, upper_bound)."""
+        w_init = _lib.as_f64(w_init)
+        m = len(self.weights)
+        if len(w_init) != m:
+            raise ValueError("w_init has the wrong length")
+        w_round = np.empty(m, np.float64)
+        w_relaxed = np.empty(m, np.float64)
+        upper = ctypes.c_double()
+        its = ctypes.c_int32()
+        self.lambda_trace = np.full(max(int(max_iters), 1), np.nan)
+        _lib.check(self._lib.cslam_mac_fw_subset(
+            self._handle, _lib.ptr(w_init), int(k), int(max_iters), float(duality_gap_tol),
+            _lib.ptr(w_round), _lib.ptr(w_relaxed), ctypes.byref(upper), ctypes.byref(its),
+            _lib.ptr(self.lambda_trace)))
+        self.fw_iters = its.value
+        self.lambda_trace = self.lambda_trace[:its.value]
+        if its.value < max_iters or (its.value > 0 and max_iters > 0 and
+                                     upper.value - self.lambda_trace[-1] < duality_gap_tol):
+            print("Duality gap tolerance reached, found optimal solution")  # mac.py:224
+        else:
+            print("Reached maximum iterations")  # mac.py:232
+        return self.round_solution_tiebreaker(w_relaxed, k), w_relaxed, upper.value
+
+    def stats(self):
+        """(solver iterations so far, device ms of the last fiedler / fw_subset call)."""
+        n = ctypes.c_int64()
+        ms = ctypes.c_double()
+        _lib.check(self._lib.cslam_mac_stats(self._handle, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+

@@ -30,6 +30,13 @@ def lib():
         L.oracle_similarities.argtypes = [fp, i64, i64, fp, i64, fp]
         L.oracle_search.argtypes = [fp, i64, i64, fp, i64, i64, ip, fp, ip]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
+        # a 1-GPU box grants 16 cores of CPU share however many the host shows
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        L.oracle_set_threads(max(1, min(avail, 16)))
         _LIB = L
     return _LIB
 

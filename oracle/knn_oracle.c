@@ -167,6 +167,14 @@ void oracle_search(const float* rows, int64_t n, int64_t d, const float* queries
     free(sims);
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

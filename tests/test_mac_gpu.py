@@ -1,0 +1,255 @@
+"""Parity of the device MAC path (through the C ABI) with outputs of the reference recorded in
+tests/golden/ (mac_ref.npz, acm_ref.json, lcsm_ref.json) and with the numpy oracle.
+
+Tolerances (north_star: Fiedler value within 1e-5): lambda_2 is checked to 1e-9 absolute
+(~1e-7 relative) against the reference's value, the Fiedler vector to 2e-5 (the reference's
+own TraceMIN stops at a 1e-8 residual, which leaves ~1e-6 in the vector), selections as sets.
+"""
+import io
+import json
+import os
+from collections import namedtuple
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from oracle import mac_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(__file__)
+G = np.load(os.path.join(HERE, "golden", "mac_ref.npz"))
+CASES = [str(c) for c in G["cases"]]
+T = json.load(open(os.path.join(HERE, "golden", "acm_ref.json")))
+
+
+def _mac(case):
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    g = lambda s: G[f"{case}_{s}"]
+    fixed = [Edge(int(i), int(j), float(w)) for i, j, w in zip(g("fi"), g("fj"), g("fw"))]
+    cand = [Edge(int(i), int(j), float(w)) for i, j, w in zip(g("ci"), g("cj"), g("cw"))]
+    return MAC(fixed, cand, int(g("nb")[4])), g
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_laplacian_matches_reference(gpu, case):
+    mac, g = _mac(case)
+    L = mac.combined_laplacian(g("w_init"))
+    L.sort_indices()
+    np.testing.assert_array_equal(L.indptr, g("L0_indptr"))
+    np.testing.assert_array_equal(L.indices, g("L0_indices"))
+    np.testing.assert_allclose(L.data, g("L0_data"), rtol=0, atol=1e-15)
+    mac.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fiedler_pair_and_gradient(gpu, case):
+    mac, g = _mac(case)
+    lam, v = mac.evaluate_fiedler_pair(g("w_init"))
+    assert abs(lam - g("lambda_trace")[0]) < 1e-9          # north_star tolerance is 1e-5
+    assert abs(lam - g("lambda_trace")[0]) / g("lambda_trace")[0] < 1e-6
+    assert abs(np.linalg.norm(v) - 1.0) < 1e-12
+    np.testing.assert_allclose(v, g("v0"), atol=2e-5)
+    grad = mac.grad_from_fiedler(g("v0"))
+    np.testing.assert_allclose(grad, g("g0"), rtol=1e-12, atol=1e-18)
+    # and on the last Frank-Wolfe iterate (a dense relaxed w)
+    lam_l, v_l = mac.evaluate_fiedler_pair(g("w_last"))
+    assert abs(lam_l - g("lambda_trace")[-1]) < 1e-9
+    assert abs(lam_l - float(g("eigsh_lambda_last"))) < 1e-9   # BASELINE cfg3 comparator
+    np.testing.assert_allclose(v_l, g("vlast"), atol=2e-5)
+    mac.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fw_subset_matches_reference(gpu, case):
+    mac, g = _mac(case)
+    k = int(g("nb")[3])
+    with redirect_stdout(io.StringIO()) as out:
+        rounded, relaxed, upper = mac.fw_subset(g("w_init"), k, max_iters=20)
+    assert "Reached maximum iterations" in out.getvalue()
+    np.testing.assert_allclose(mac.lambda_trace, g("lambda_trace"), atol=1e-9)
+    np.testing.assert_allclose(relaxed, g("relaxed"), atol=1e-9)
+    assert abs(upper - float(g("upper"))) < 1e-8
+    np.testing.assert_array_equal(rounded, g("rounded"))       # same selected set
+    assert rounded.sum() == k
+    mac.close()
+
+
+def test_round_solution_and_topk(gpu):
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    rs = np.random.RandomState(1)
+    mac = MAC([Edge(0, 1, 1.0)], [Edge(0, 1, 0.5)], 2)
+    for m, k in ((1, 1), (10, 3), (1000, 1000), (5000, 17), (200000, 500)):
+        x = rs.randn(m)
+        mask = mac.round_solution(x, k)
+        ref = np.zeros(m)
+        ref[np.argsort(-x, kind="stable")[:k]] = 1.0
+        np.testing.assert_array_equal(mask, ref)
+    x = np.array([1.0, 3.0, 3.0, 3.0, 0.0, 3.0, -1.0])      # ties → lowest index kept
+    np.testing.assert_array_equal(mac.round_solution(x, 3), [0, 1, 1, 1, 0, 0, 0])
+    np.testing.assert_array_equal(mac.round_solution(x, 0), np.zeros(7))
+    mac.close()
+
+
+def test_disconnected_raises_and_recovers(gpu):
+    from cslam_amd import _lib
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    fixed = [Edge(0, 1, 1.0), Edge(1, 2, 1.0), Edge(3, 4, 1.0), Edge(4, 5, 1.0)]
+    mac = MAC(fixed, [Edge(0, 5, 0.5)], 6)
+    with pytest.raises(RuntimeError) as ei:
+        mac.evaluate_fiedler_pair(np.zeros(1))
+    assert isinstance(ei.value, _lib.GraphDisconnectedError)
+    lam, v = mac.evaluate_fiedler_pair(np.ones(1))            # same handle still works
+    ora = mo.MacOracle([0, 1, 3, 4], [1, 2, 4, 5], np.ones(4), [0], [5], [0.5], 6)
+    assert abs(lam - ora.evaluate_fiedler_pair(np.ones(1))[0]) < 1e-10
+    # isolated trailing node (the excluded-robot shape of SURVEY.md Appendix A)
+    mac2 = MAC(fixed + [Edge(2, 3, 1.0)], [Edge(0, 5, 0.5)], 7)
+    with pytest.raises(_lib.GraphDisconnectedError):
+        mac2.evaluate_fiedler_pair(np.ones(1))
+    mac.close()
+    mac2.close()
+
+
+def test_find_fiedler_pair_of_arbitrary_laplacian(gpu):
+    from cslam_amd.mac.mac import MAC
+    mac, g = _mac("g3x100")
+    L = mac.combined_laplacian(g("w_init"))
+    lam, v = mac.find_fiedler_pair(L)
+    assert abs(lam - g("lambda_trace")[0]) < 1e-9
+    mac.close()
+
+
+def _E(lst):
+    from cslam_amd.algebraic_connectivity_maximization import EdgeInterRobot
+    return EdgeInterRobot(int(lst[0]), int(lst[1]), int(lst[2]), int(lst[3]), float(lst[4]))
+
+
+def _keys(edges):
+    return sorted((e.robot0_id, e.robot0_keyframe_id, e.robot1_id, e.robot1_keyframe_id)
+                  for e in edges)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_select_candidates_end_to_end(gpu, case):
+    """AlgebraicConnectivityMaximization.select_candidates on the reference's graph gives the
+    reference's selection (MAC branch: every robot has a fixed inter-robot edge)."""
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization
+    g = lambda s: G[f"{case}_{s}"]
+    nb_robots, k = int(g("nb")[2]), int(g("nb")[3])
+    acm = AlgebraicConnectivityMaximization(0, nb_robots)
+    acm.set_graph([_E(x) for x in g("fixed_edges")], [_E(x) for x in g("cand_edges")])
+    with redirect_stdout(io.StringIO()):
+        sel = acm.select_candidates(k, {r: True for r in range(nb_robots)})
+    assert _keys(sel) == _keys([_E(x) for x in g("selected")])
+    assert len(acm.candidate_edges) == len(g("cand_edges")) - k
+
+
+def test_excluded_robot_ladder(gpu):
+    """Known-but-excluded robot → disconnected L → k exceptions → initial greedy."""
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization
+    t = T["excluded_robot"]
+    np.random.seed(1234)
+    acm = AlgebraicConnectivityMaximization(t["robot_id"], t["max_nb_robots"])
+    acm.set_graph([_E(x) for x in t["fixed"]], [_E(x) for x in t["cand"]])
+    with redirect_stdout(io.StringIO()):
+        sel = acm.select_candidates(t["budget"], {int(k): v for k, v in t["in_range"].items()})
+    assert acm.last_solver_exceptions == t["budget"]
+    assert _keys(sel) == _keys([_E(x) for x in t["selected"]])
+    assert len(acm.candidate_edges) == t["remaining"]
+
+
+def test_lifecycle_select_fix_remove(gpu):
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization
+    t = T["lifecycle"]
+    acm = AlgebraicConnectivityMaximization(t["robot_id"], t["max_nb_robots"])
+    acm.set_graph([_E(x) for x in t["fixed"]], [_E(x) for x in t["cand"]])
+    for rd in t["rounds"]:
+        with redirect_stdout(io.StringIO()):
+            sel = acm.select_candidates(t["budget"], {0: True, 1: True, 2: True})
+        assert _keys(sel) == _keys([_E(x) for x in rd["selected"]])
+        # replay the reference's feedback in the reference's order
+        ref_sel = [_E(x) for x in rd["selected"]]
+        acm.candidate_edges_to_fixed([e for i, e in enumerate(ref_sel) if i % 2 == 0])
+        acm.remove_candidate_edges([e for i, e in enumerate(ref_sel) if i % 2 == 1], failed=True)
+        assert len(acm.fixed_edges) == rd["nb_fixed"] and len(acm.candidate_edges) == rd["nb_cand"]
+
+
+def test_loop_closure_sparse_matching_end_to_end(gpu):
+    """cfg1-shaped replay of the reference's LoopClosureSparseMatching (3 robots x 120 kf)."""
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    ref = json.load(open(os.path.join(HERE, "golden", "lcsm_ref.json")))
+    desc = np.load(os.path.join(HERE, "golden", "lcsm_desc.npz"))["desc"]
+    Msg = namedtuple("GlobalDescriptor", ["keyframe_id", "robot_id", "descriptor"])
+
+    class Node:
+        def get_logger(self):
+            class L:
+                def info(self, *a, **k):
+                    pass
+                debug = error = info
+            return L()
+
+    l = LoopClosureSparseMatching(ref["params"], Node())
+    ev = iter(ref["events"])
+    near_ties = 0
+    for kf in range(desc.shape[1]):
+        ms = l.add_local_global_descriptor(desc[0, kf], kf)
+        e = next(ev)
+        assert e[0] == "local" and e[1] == kf
+        assert [list(map(int, m[:4])) for m in ms] == [list(map(int, x[:4])) for x in e[2]]
+        for m, x in zip(ms, e[2]):
+            assert abs(m.weight - x[4]) < 1e-6
+        kf_match, sims = l.match_local_loop_closures(desc[0, kf], kf)
+        e = next(ev)
+        assert e[0] == "intra"
+        np.testing.assert_allclose(sims, e[3], atol=1e-6)
+        assert (None if kf_match is None else int(kf_match)) == e[2]
+        for r in (1, 2):
+            m = l.add_other_robot_global_descriptor(Msg(kf, r, desc[r, kf].tolist()))
+            e = next(ev)
+            assert e[0] == "other" and e[1] == r
+            if e[3] is None:
+                assert m is None
+            else:
+                assert m is not None and abs(m.weight - e[3][4]) < 1e-6
+                if list(map(int, m[:4])) != list(map(int, e[3][:4])):
+                    near_ties += 1
+    assert near_ties == 0
+    cand = {str(k): float(v.weight) for k, v in l.candidate_selector.candidate_edges.items()}
+    assert set(cand) == set(ref["candidates"])
+    for k in cand:
+        assert abs(cand[k] - ref["candidates"][k]) < 1e-6
+    sel = l.select_candidates(10, {0: True, 1: True, 2: True})
+    assert _keys(sel) == _keys([_E(x) for x in ref["selected"]])
+
+
+def test_batched_other_robot_descriptors_equal_serial(gpu):
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    desc = np.load(os.path.join(HERE, "golden", "lcsm_desc.npz"))["desc"]
+    Msg = namedtuple("GlobalDescriptor", ["keyframe_id", "robot_id", "descriptor"])
+    params = {"robot_id": 0, "max_nb_robots": 3, "frontend.sensor_type": "stereo",
+              "frontend.similarity_threshold": 0.6, "frontend.nb_best_matches": 10,
+              "frontend.intra_loop_min_inbetween_keyframes": 10}
+
+    class Node:
+        def get_logger(self):
+            class L:
+                def info(self, *a, **k):
+                    pass
+            return L()
+
+    a = LoopClosureSparseMatching(params, Node())
+    b = LoopClosureSparseMatching(params, Node())
+    for kf in range(60):
+        a.local_nnsm.add_item(desc[0, kf], kf)
+        b.local_nnsm.add_item(desc[0, kf], kf)
+    msgs = [Msg(kf, 1 + (kf % 2), desc[1 + (kf % 2), kf].tolist()) for kf in range(40)]
+    serial = [a.add_other_robot_global_descriptor(m) for m in msgs]
+    batched = b.add_other_robot_global_descriptors(msgs)
+    assert [None if x is None else tuple(x) for x in serial] == \
+           [None if x is None else tuple(x) for x in batched]
+    assert a.candidate_selector.candidate_edges == b.candidate_selector.candidate_edges
