@@ -121,23 +121,125 @@ __global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_pt
         atomicMax(&sc->lnorm_bits, (unsigned long long)__double_as_longlong(2.0 * mx));
 }
 
-// LDL^T of the block-tridiagonal M, one thread per chain segment (sequential recurrence)
-__global__ void k_factor(const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
-                         int nseg, const double* __restrict__ a, const double* __restrict__ b,
-                         double* __restrict__ l, double* __restrict__ invd, Scalars* sc) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseg) return;
-    int i0 = seg_start[s], len = seg_len[s];
-    double d = a[i0];
-    bool bad = !(d > 0.0);
-    invd[i0] = 1.0 / d;
-    for (int t = 1; t < len; ++t) {
-        int i = i0 + t;
-        double li = b[i - 1] / d;
-        l[i - 1] = li;
-        d = a[i] - li * b[i - 1];
-        bad |= !(d > 0.0);
-        invd[i] = 1.0 / d;
+// --------------------------------------------------------------------------------------------
+// LDL^T of the block-tridiagonal M by a parallel scan.  The pivot recurrence
+//   d_i = a_i - b_{i-1}^2 / d_{i-1}
+// is a Moebius map of d_{i-1}; with d = p/q it is linear: [p;q] <- [[a_i, -b_{i-1}^2],[1,0]] [p;q].
+// Segment composites are 2x2 products (rescaled by their largest entry: only the ratio p/q
+// matters); each thread then re-runs the true recurrence over its own elements from the
+// scanned incoming ratio.  b_{i-1} = 0 (chain boundary) makes the map constant → automatic
+// restart.  Pivots of a diagonally dominant M are >= ~|b|, so the ~1e-12 relative error of the
+// composites (near-double-root cancellation on long unit chains) is harmless: L D L^T is the
+// exact factorisation of a matrix within 1e-12 of M, still SPD, still a fixed preconditioner.
+// --------------------------------------------------------------------------------------------
+struct Mat2 {
+    double a, b, c, d;  // [[a, b], [c, d]]
+};
+__device__ inline Mat2 mat_mul_norm(const Mat2& first, const Mat2& then) {  // then * first
+    Mat2 r{then.a * first.a + then.b * first.c, then.a * first.b + then.b * first.d,
+           then.c * first.a + then.d * first.c, then.c * first.b + then.d * first.d};
+    double mx = fmax(fmax(fabs(r.a), fabs(r.b)), fmax(fabs(r.c), fabs(r.d)));
+    if (mx > 0.0) {
+        double inv = 1.0 / mx;
+        r.a *= inv;
+        r.b *= inv;
+        r.c *= inv;
+        r.d *= inv;
+    }
+    return r;
+}
+__device__ inline Mat2 fact_elem(int i, const double* __restrict__ a, const double* __restrict__ b) {
+    const double bb = i > 0 ? b[i - 1] : 0.0;
+    return Mat2{a[i], -bb * bb, 1.0, 0.0};
+}
+constexpr int kFactElems = 8;
+constexpr int kFactBlock = kScanThreads * kFactElems;
+
+__device__ inline Mat2 block_scan_mat(Mat2 v, Mat2* smem /* [256] */) {
+    const int tid = threadIdx.x;
+    smem[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        Mat2 o = smem[tid >= off ? tid - off : 0];
+        __syncthreads();
+        if (tid >= off) v = mat_mul_norm(o, v);
+        smem[tid] = v;
+        __syncthreads();
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_fact_agg(const double* __restrict__ a,
+                                                           const double* __restrict__ b, int n,
+                                                           Mat2* __restrict__ agg) {
+    __shared__ Mat2 smem[kScanThreads];
+    const int i0 = blockIdx.x * kFactBlock + threadIdx.x * kFactElems;
+    Mat2 t{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int e = 0; e < kFactElems; ++e)
+        if (i0 + e < n) t = mat_mul_norm(t, fact_elem(i0 + e, a, b));
+    Mat2 inc = block_scan_mat(t, smem);
+    if (threadIdx.x == kScanThreads - 1) agg[blockIdx.x] = inc;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_fact_apply(const double* __restrict__ a,
+                                                             const double* __restrict__ b, int n,
+                                                             const Mat2* __restrict__ agg,
+                                                             double* __restrict__ l,
+                                                             double* __restrict__ invd,
+                                                             Scalars* sc) {
+    __shared__ Mat2 smem[kScanThreads];
+    __shared__ double pin_s, qin_s;
+    {
+        double p = 1.0, q = 1.0;  // any p != 0 works: element 0 has b_{-1} = 0
+        for (int b0 = 0; b0 < (int)blockIdx.x; b0 += kScanThreads) {
+            const int cnt = min(kScanThreads, (int)blockIdx.x - b0);
+            __syncthreads();
+            if ((int)threadIdx.x < cnt) smem[threadIdx.x] = agg[b0 + threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int k = 0; k < cnt; ++k) {
+                    const Mat2 m = smem[k];
+                    double np = m.a * p + m.b * q, nq = m.c * p + m.d * q;
+                    double mx = fmax(fabs(np), fabs(nq));
+                    if (mx > 0.0) {
+                        np /= mx;
+                        nq /= mx;
+                    }
+                    p = np;
+                    q = nq;
+                }
+        }
+        if (threadIdx.x == 0) {
+            pin_s = p;
+            qin_s = q;
+        }
+        __syncthreads();
+    }
+    const int i0 = blockIdx.x * kFactBlock + threadIdx.x * kFactElems;
+    Mat2 t{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int e = 0; e < kFactElems; ++e)
+        if (i0 + e < n) t = mat_mul_norm(t, fact_elem(i0 + e, a, b));
+    (void)block_scan_mat(t, smem);
+    const Mat2 exc = threadIdx.x > 0 ? smem[threadIdx.x - 1] : Mat2{1.0, 0.0, 0.0, 1.0};
+    const double p = exc.a * pin_s + exc.b * qin_s;
+    const double q = exc.c * pin_s + exc.d * qin_s;
+    double d = p / q;  // d_{i0-1}; unused when b_{i0-1} == 0 (and for i0 == 0)
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < kFactElems; ++e) {
+        const int i = i0 + e;
+        if (i < n) {
+            const double bb = i > 0 ? b[i - 1] : 0.0;
+            double li = 0.0;
+            if (bb != 0.0) li = bb / d;
+            if (i > 0) l[i - 1] = li;
+            d = a[i] - li * bb;
+            bad |= !(d > 0.0);
+            invd[i] = 1.0 / d;
+        }
     }
     if (bad) sc->factor_bad = 1;
 }
@@ -214,10 +316,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const double* __res
     __shared__ Aff smem[kScanThreads];
     __shared__ double red[4];
     __shared__ double vin_s;
-    if (threadIdx.x == 0) {
+    // value entering this block = preceding block composites applied in order to 0; the
+    // composites are staged through LDS 256 at a time (a dependent chain of global loads by
+    // one lane costs ~0.5 us per link)
+    {
         double v = 0.0;
-        for (int b = 0; b < (int)blockIdx.x; ++b) v = agg[b].m * v + agg[b].c;
-        vin_s = v;
+        for (int b0 = 0; b0 < (int)blockIdx.x; b0 += kScanThreads) {
+            const int cnt = min(kScanThreads, (int)blockIdx.x - b0);
+            __syncthreads();
+            if ((int)threadIdx.x < cnt) smem[threadIdx.x] = agg[b0 + threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int b = 0; b < cnt; ++b) v = smem[b].m * v + smem[b].c;
+        }
+        if (threadIdx.x == 0) vin_s = v;
+        __syncthreads();
     }
     const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
     Aff el[kScanElems];
@@ -274,10 +387,12 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_pt
 //   partial[b][0..5]  = S^T S   (xx, xw, xp, ww, wp, pp)
 //   partial[b][6..11] = S^T AS  (xAx, xAw, xAp, wAw, wAp, pAp)
 // --------------------------------------------------------------------------------------------
+// mean of the scan output from its per-block partial sums; every lane of the calling wave
+// takes part (lane-strided loads + butterfly: deterministic), all lanes return the value
 __device__ inline double mean_from_psum(const double* psum, int nscan, int n) {
     double s = 0.0;
-    for (int b = 0; b < nscan; ++b) s += psum[b];
-    return s / (double)n;
+    for (int b = threadIdx.x & 63; b < nscan; b += 64) s += psum[b];
+    return wave_sum(s) / (double)n;
 }
 
 __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
@@ -361,16 +476,22 @@ __device__ inline void jacobi_smallest(int k, double A[3][3], double* theta, dou
     for (int i = 0; i < k; ++i) u[i] = V[i][best];
 }
 
-__global__ void k_rr_solve(const double* __restrict__ partial, int nblk,
+__global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ partial, int nblk,
                            const double* __restrict__ psum, int nscan, int use_mu, int n,
                            Scalars* sc) {
     if (sc->done) return;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double smem[12 * 4];
     double g[12];
+#pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = 0.0;
-    for (int b = 0; b < nblk; ++b)
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+#pragma unroll
         for (int i = 0; i < 12; ++i) g[i] += partial[b * 12 + i];
-    sc->mu = use_mu ? mean_from_psum(psum, nscan, n) : 0.0;
+    }
+    block_sum<12>(g, smem);
+    const double mu = use_mu ? mean_from_psum(psum, nscan, n) : 0.0;
+    if (threadIdx.x != 0) return;
+    sc->mu = mu;
     const double GB[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
     const double GA[3][3] = {{g[6], g[7], g[8]}, {g[7], g[9], g[10]}, {g[8], g[10], g[11]}};
     // active basis vectors: non-negligible norm relative to x
@@ -488,11 +609,15 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ x, const do
     if (threadIdx.x == 0) rpart[blockIdx.x] = v[0];
 }
 
-__global__ void k_check(const double* __restrict__ rpart, int nblk, Scalars* sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_check(const double* __restrict__ rpart, int nblk,
+                                               Scalars* sc) {
     if (sc->done) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += rpart[b];
+    __shared__ double smem[4];
+    double v[1] = {0.0};
+    for (int b = threadIdx.x; b < nblk; b += 256) v[0] += rpart[b];
+    block_sum<1>(v, smem);
+    if (threadIdx.x != 0) return;
+    const double s = v[0];
     double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
     sc->lnorm = lnorm;
     sc->res = s / lnorm;
@@ -649,12 +774,12 @@ struct cslam_mac {
     int32_t *ci_d = nullptr, *cj_d = nullptr;
     double *cw_d = nullptr, *ew = nullptr;
     uint8_t* link = nullptr;
-    int32_t *seg_start = nullptr, *seg_len = nullptr;
-    int nseg = 0;
     double *a = nullptr, *b = nullptr, *l = nullptr, *invd = nullptr;
     double *x = nullptr, *w = nullptr, *p = nullptr, *Ax = nullptr, *Aw = nullptr, *Ap = nullptr,
            *r = nullptr, *y = nullptr;
     Aff *agg_f = nullptr, *agg_b = nullptr;
+    Mat2* agg_m = nullptr;
+    int nfact = 0;
     double *psum = nullptr, *partial = nullptr, *rpart = nullptr;
     Scalars* sc = nullptr;
     double *wvec = nullptr, *gvec = nullptr, *svec = nullptr;  // FW state [m]
@@ -725,11 +850,11 @@ void launch_iteration(cslam_mac* mac, hipStream_t st) {
                        mac->adj_eid, mac->ew, mac->w, mac->Aw, n, mac->sc);
     hipLaunchKernelGGL(k_dots, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax, mac->Aw,
                        mac->Ap, n, mac->psum, mac->nscan, 1, mac->partial, mac->sc);
-    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(64), 0, st, mac->partial, mac->nred, mac->psum,
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
                        mac->nscan, 1, n, mac->sc);
     hipLaunchKernelGGL(k_update, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax,
                        mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, mac->rpart, mac->nred, mac->sc);
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
 }
 
 int build_graph(cslam_mac* mac) {
@@ -768,9 +893,10 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
     CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_diag, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->adj_eid,
                        mac->ew, mac->link, n, mac->a, mac->b, mac->sc);
-    hipLaunchKernelGGL(k_factor, dim3((unsigned)((mac->nseg + 63) / 64)), dim3(64), 0, st,
-                       mac->seg_start, mac->seg_len, mac->nseg, mac->a, mac->b, mac->l, mac->invd,
-                       mac->sc);
+    hipLaunchKernelGGL(k_fact_agg, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
+                       mac->b, n, mac->agg_m);
+    hipLaunchKernelGGL(k_fact_apply, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
+                       mac->b, n, mac->agg_m, mac->l, mac->invd, mac->sc);
     // bootstrap: Ax = L x, 1x1 Rayleigh-Ritz (w = p = 0), r = Ax - theta x
     CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
     CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
@@ -780,15 +906,14 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
                        mac->adj_eid, mac->ew, mac->x, mac->Ax, n, mac->sc);
     hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
                        mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
-    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(64), 0, st, mac->partial, mac->nred, mac->psum,
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
                        mac->nscan, 0, n, mac->sc);
     hipLaunchKernelGGL(k_update, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
                        mac->Ax, mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, mac->rpart, mac->nred, mac->sc);
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
     CSLAM_HIP_TRY(hipGetLastError());
     CSLAM_TRY(build_graph(mac));
     Scalars h;
-    int replays = 0;
     while (true) {
         CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
         CSLAM_HIP_TRY(hipStreamSynchronize(st));
@@ -797,7 +922,6 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
                         "tridiagonal pivot <= 0: L(w) has an isolated node (disconnected graph)");
         if (h.done) break;
         CSLAM_HIP_TRY(hipGraphLaunch(mac->graph, st));
-        ++replays;
     }
     mac->spmv_count += h.iters;
     if (iters_out) *iters_out = h.iters;
@@ -913,16 +1037,8 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
         int i = fixed_i[e], j = fixed_j[e];
         if (std::abs(i - j) == 1 && fixed_w[e] > 0.0) link[std::min(i, j)] = 1;
     }
-    std::vector<int32_t> seg_start, seg_len;
-    for (int i = 0; i < n;) {
-        int j = i;
-        while (j + 1 < n && link[j]) ++j;
-        seg_start.push_back(i);
-        seg_len.push_back(j - i + 1);
-        i = j + 1;
-    }
-    mac->nseg = (int)seg_start.size();
     mac->nscan = (n + kScanBlock - 1) / kScanBlock;
+    mac->nfact = (n + kFactBlock - 1) / kFactBlock;
     mac->nred = std::min(kRedBlocksMax, (n + 255) / 256);
 
     int rc = CSLAM_OK;
@@ -942,13 +1058,12 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->cw_d, n_cand));
     A(dev_alloc(&mac->ew, E));
     A(dev_alloc(&mac->link, n));
-    A(dev_alloc(&mac->seg_start, seg_start.size()));
-    A(dev_alloc(&mac->seg_len, seg_len.size()));
     for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
                        &mac->Aw, &mac->Ap, &mac->r, &mac->y})
         A(dev_alloc(v, n));
     A(dev_alloc(&mac->agg_f, mac->nscan));
     A(dev_alloc(&mac->agg_b, mac->nscan));
+    A(dev_alloc(&mac->agg_m, mac->nfact));
     A(dev_alloc(&mac->psum, mac->nscan));
     A(dev_alloc(&mac->partial, (size_t)mac->nred * 12));
     A(dev_alloc(&mac->rpart, mac->nred));
@@ -972,8 +1087,6 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     H2D(mac->cw_d, cand_w, n_cand * 8);
     H2D(mac->ew, fixed_w, n_fixed * 8);
     H2D(mac->link, link.data(), n);
-    H2D(mac->seg_start, seg_start.data(), seg_start.size() * 4);
-    H2D(mac->seg_len, seg_len.data(), seg_len.size() * 4);
     std::vector<double> x0;
     cold_start_vector(n, x0);
     H2D(mac->x, x0.data(), (size_t)n * 8);
@@ -998,10 +1111,10 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
     for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
                     (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->link,
-                    (void*)mac->seg_start, (void*)mac->seg_len, (void*)mac->a, (void*)mac->b,
+                    (void*)mac->a, (void*)mac->b,
                     (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
                     (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
-                    (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->psum, (void*)mac->partial,
+                    (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->agg_m, (void*)mac->psum, (void*)mac->partial,
                     (void*)mac->rpart, (void*)mac->sc, (void*)mac->wvec, (void*)mac->gvec,
                     (void*)mac->svec})
         if (p) (void)hipFree(p);
