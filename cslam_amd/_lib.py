@@ -55,6 +55,8 @@ SIGNATURES = {
     "cslam_pool_device_view": (_c.c_int, [_vp, _c.POINTER(_vp), _i64p]),
     "cslam_pool_search": (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _vp, _vp, _vp]),
     "cslam_pool_search_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp, _vp]),
+    "cslam_pool_search_range_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64,
+                                               _c.c_int64, _vp, _vp, _vp]),
     "cslam_pool_similarities_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int64, _vp]),
     "cslam_pool_profile_begin": (_c.c_int, [_vp, _c.c_int]),
     "cslam_pool_profile_end": (_c.c_int, [_vp, _f64p, _c.POINTER(_c.c_int)]),

@@ -325,7 +325,7 @@ template <bool FROM_SIMS, bool FINAL>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
                                                 int64_t sims_stride,
                                                 const float* __restrict__ rnx,
-                                                const float* __restrict__ rnq,
+                                                const float* __restrict__ rnq, uint32_t row0,
                                                 const uint64_t* __restrict__ cin,
                                                 int64_t cin_stride, int64_t n_in, int k,
                                                 uint64_t* __restrict__ cout, int64_t cout_stride,
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
         uint64_t c = 0;
         if (i < n_in) {
             if (FROM_SIMS)
-                c = make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], (uint32_t)i);
+                c = make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], row0 + (uint32_t)i);
             else
                 c = cin[q * cin_stride + i];
         }
@@ -396,13 +396,15 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
 __global__ __launch_bounds__(256) void k_make_comp(const float* __restrict__ sims,
                                                    int64_t sims_stride,
                                                    const float* __restrict__ rnx,
-                                                   const float* __restrict__ rnq, int64_t n,
-                                                   int64_t npow2, uint64_t* __restrict__ comp) {
+                                                   const float* __restrict__ rnq, uint32_t row0,
+                                                   int64_t n, int64_t npow2,
+                                                   uint64_t* __restrict__ comp) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t q = blockIdx.y;
     if (i >= npow2) return;
     comp[q * npow2 + i] =
-        (i < n) ? make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], (uint32_t)i) : 0ull;
+        (i < n) ? make_comp((sims[q * sims_stride + i] * rnx[i]) * rnq[q], row0 + (uint32_t)i)
+                : 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_bitonic_step(uint64_t* __restrict__ comp, int64_t npow2,
@@ -454,6 +456,7 @@ struct cslam_pool {
     int dim = 0, dp = 0, device = 0, cus = 256;
     int64_t n = 0, cap = 0;
     int64_t xs = 0;             // row stride in floats (dp + anti-camping pad)
+    int64_t v0 = 0, vn = 0;     // row window [v0, v0+vn) of the search in flight
     float* rows = nullptr;      // [cap][dp]
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
@@ -506,7 +509,7 @@ template <int T, int S, int U>
 void launch_scan_t(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
                    int64_t n_waves, hipStream_t st) {
     unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL((k_scan<T, S, U>), dim3(blocks), dim3(256), 0, st, p->rows, p->xs, p->n,
+    hipLaunchKernelGGL((k_scan<T, S, U>), dim3(blocks), dim3(256), 0, st, p->rows + p->v0 * p->xs, p->xs, p->vn,
                        p->dp, Q, m_valid, dots, dots_stride, n_waves);
 }
 
@@ -529,7 +532,7 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
     const int wpc = wpc_env > 0 ? wpc_env : 4;  // measured best at S=4 (profiles/r01_scan_sweep.txt)
     const int S = s_env > 0 ? s_env : 4;
-    int64_t groups = (p->n + 16 * S - 1) / (16 * S);
+    int64_t groups = (p->vn + 16 * S - 1) / (16 * S);
     int64_t resident = (int64_t)p->cus * wpc;
     int64_t n_waves = groups < resident ? groups : resident;
     if (n_waves < 1) n_waves = 1;
@@ -582,14 +585,14 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
 
 int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
                    int32_t* out_idx, float* out_sim, hipStream_t st) {
-    const float* rnx = p->inv_norm;
+    const float* rnx = p->inv_norm + p->v0;
     const float* rnq = p->rnq.as<float>();
-    int64_t n_in = p->n;
+    int64_t n_in = p->vn;
     int64_t parts = (n_in + kSelectPart - 1) / kSelectPart;
     if (parts <= 1) {
         hipLaunchKernelGGL((k_select<true, true>), dim3(1, m), dim3(256), 0, st, sims,
-                           sims_stride, rnx, rnq, nullptr, (int64_t)0, n_in, k, nullptr,
-                           (int64_t)0, out_idx, out_sim);
+                           sims_stride, rnx, rnq, (uint32_t)p->v0, nullptr, (int64_t)0, n_in, k,
+                           nullptr, (int64_t)0, out_idx, out_sim);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -597,7 +600,7 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
     int64_t cstride = parts * k;
     CSLAM_TRY(p->cand_a.reserve((size_t)m * cstride * sizeof(uint64_t)));
     hipLaunchKernelGGL((k_select<true, false>), dim3((unsigned)parts, m), dim3(256), 0, st, sims,
-                       sims_stride, rnx, rnq, nullptr, (int64_t)0, n_in, k,
+                       sims_stride, rnx, rnq, (uint32_t)p->v0, nullptr, (int64_t)0, n_in, k,
                        p->cand_a.as<uint64_t>(), cstride, nullptr, nullptr);
     CSLAM_HIP_TRY(hipGetLastError());
     DevBuf* src = &p->cand_a;
@@ -608,16 +611,16 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
         parts = (n_in + kSelectPart - 1) / kSelectPart;
         if (parts <= 1) {
             hipLaunchKernelGGL((k_select<false, true>), dim3(1, m), dim3(256), 0, st, nullptr,
-                               (int64_t)0, nullptr, nullptr, src->as<uint64_t>(), in_stride, n_in,
-                               k, nullptr, (int64_t)0, out_idx, out_sim);
+                               (int64_t)0, nullptr, nullptr, 0u, src->as<uint64_t>(), in_stride,
+                               n_in, k, nullptr, (int64_t)0, out_idx, out_sim);
             CSLAM_HIP_TRY(hipGetLastError());
             return CSLAM_OK;
         }
         int64_t ostride = parts * k;
         CSLAM_TRY(dst->reserve((size_t)m * ostride * sizeof(uint64_t)));
         hipLaunchKernelGGL((k_select<false, false>), dim3((unsigned)parts, m), dim3(256), 0, st,
-                           nullptr, (int64_t)0, nullptr, nullptr, src->as<uint64_t>(), in_stride,
-                           n_in, k, dst->as<uint64_t>(), ostride, nullptr, nullptr);
+                           nullptr, (int64_t)0, nullptr, nullptr, 0u, src->as<uint64_t>(),
+                           in_stride, n_in, k, dst->as<uint64_t>(), ostride, nullptr, nullptr);
         CSLAM_HIP_TRY(hipGetLastError());
         DevBuf* t = src;
         src = dst;
@@ -629,15 +632,15 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
 
 int select_any_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
                  int32_t* out_idx, float* out_sim, hipStream_t st) {
-    const float* rnx = p->inv_norm;
+    const float* rnx = p->inv_norm + p->v0;
     const float* rnq = p->rnq.as<float>();
     int64_t npow2 = 1;
-    while (npow2 < p->n) npow2 <<= 1;
+    while (npow2 < p->vn) npow2 <<= 1;
     if (npow2 < 2) npow2 = 2;
     CSLAM_TRY(p->comp.reserve((size_t)m * npow2 * sizeof(uint64_t)));
     uint64_t* comp = p->comp.as<uint64_t>();
     hipLaunchKernelGGL(k_make_comp, dim3((unsigned)((npow2 + 255) / 256), m), dim3(256), 0, st,
-                       sims, sims_stride, rnx, rnq, p->n, npow2, comp);
+                       sims, sims_stride, rnx, rnq, (uint32_t)p->v0, p->vn, npow2, comp);
     for (int64_t size = 2; size <= npow2; size <<= 1)
         for (int64_t stride = size >> 1; stride > 0; stride >>= 1)
             hipLaunchKernelGGL(k_bitonic_step, dim3((unsigned)((npow2 / 2 + 255) / 256), m),
@@ -649,16 +652,21 @@ int select_any_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, i
 }
 
 int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k,
-                    int32_t* out_idx, float* out_sim, hipStream_t st) {
+                    int32_t* out_idx, float* out_sim, hipStream_t st, int64_t row_lo = 0,
+                    int64_t row_hi = -1) {
     if (m <= 0 || k <= 0) return CSLAM_OK;
-    if (p->n == 0) {
+    if (row_hi < 0 || row_hi > p->n) row_hi = p->n;
+    if (row_lo < 0) row_lo = 0;
+    p->v0 = row_lo;
+    p->vn = row_hi > row_lo ? row_hi - row_lo : 0;
+    if (p->vn == 0) {
         int64_t total = (int64_t)m * k;
         hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            total, out_idx, out_sim);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
-    int64_t sims_stride = (p->n + 63) / 64 * 64;
+    int64_t sims_stride = (p->vn + 63) / 64 * 64;
     int64_t chunk = m < kQueryChunk ? m : kQueryChunk;
     CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
     float* sims = p->sims.as<float>();
@@ -814,6 +822,19 @@ int cslam_pool_search_dev(cslam_pool_t* p, const float* queries_dev, int64_t que
                            st);
 }
 
+int cslam_pool_search_range_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
+                                int n_queries, int k, int64_t row_lo, int64_t row_hi,
+                                int32_t* out_idx_dev, float* out_sim_dev, void* stream) {
+    if (!p || n_queries < 0 || k < 0 || row_lo < 0 || row_hi < row_lo || row_hi > p->n ||
+        (n_queries > 0 && (!queries_dev || query_stride < p->dim)) ||
+        ((int64_t)n_queries * k > 0 && (!out_idx_dev || !out_sim_dev)))
+        return fail(CSLAM_E_INVALID, "pool_search_range_dev: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev, st,
+                           row_lo, row_hi);
+}
+
 int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
                                 int n_queries, float* sims_dev, int64_t sims_stride,
                                 void* stream) {
@@ -823,6 +844,8 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
     if (n_queries == 0 || p->n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    p->v0 = 0;
+    p->vn = p->n;
     for (int q0 = 0; q0 < n_queries; q0 += (int)kQueryChunk) {
         int mb = n_queries - q0 < (int)kQueryChunk ? n_queries - q0 : (int)kQueryChunk;
         float* out = sims_dev + (int64_t)q0 * sims_stride;

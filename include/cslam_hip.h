@@ -82,6 +82,12 @@ int cslam_pool_search(cslam_pool_t* pool, const float* queries, int n_queries, i
 int cslam_pool_search_dev(cslam_pool_t* pool, const float* queries_dev, int64_t query_stride,
                           int n_queries, int k, int32_t* out_idx_dev, float* out_sim_dev,
                           void* stream);
+/* search restricted to pool rows [row_lo, row_hi) (returned indices are absolute row numbers).
+ * Used by the sharded multi-robot step: "rows appended since the step started". */
+int cslam_pool_search_range_dev(cslam_pool_t* pool, const float* queries_dev,
+                                int64_t query_stride, int n_queries, int k, int64_t row_lo,
+                                int64_t row_hi, int32_t* out_idx_dev, float* out_sim_dev,
+                                void* stream);
 /* Similarities only: sims_dev[q * sims_stride + row] for row < size (all rows, unsorted). */
 int cslam_pool_similarities_dev(cslam_pool_t* pool, const float* queries_dev,
                                 int64_t query_stride, int n_queries, float* sims_dev,

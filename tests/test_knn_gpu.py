@@ -153,3 +153,37 @@ def test_device_resident_queries(gpu):
     np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
     assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
     m.close()
+
+
+def test_range_search_and_sharded_step_on_gpu(gpu):
+    """cslam_pool_search_range_dev (rows appended since the step began) and the single-rank
+    step of cslam_amd/multi_robot.py on the real pool."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd.multi_robot import HipPoolMatcher, ShardedLoopClosureMatching
+    rs = np.random.RandomState(4)
+    X = rs.rand(700, 96).astype(np.float32)
+    Q = rs.rand(9, 96).astype(np.float32)
+    hm = HipPoolMatcher(96)
+    hm.add_rows(torch.from_numpy(X[:500]).cuda(), list(range(500)))
+    hm.add_rows(torch.from_numpy(X[500:]).cuda(), list(range(500, 700)))
+    q = torch.from_numpy(Q).cuda()
+    for lo, hi in ((0, 700), (0, 500), (500, 700), (123, 124), (650, 700)):
+        rows, sims = hm.search_best(q, lo, hi)
+        o_idx, o_sim, _ = oracle_knn.search(X[lo:hi], Q, 1)
+        np.testing.assert_array_equal(rows, o_idx[:, 0] + lo)
+        assert sims.tobytes() == o_sim[:, 0].tobytes()
+    rows, sims = hm.search_best(q, 5, 5)
+    assert np.all(rows == -1)
+
+    class Solo:
+        rank, world = 0, 1
+
+        def __init__(self):
+            self.torch = torch
+
+        def all_gather(self, t):
+            return t.unsqueeze(0)
+
+    sh = ShardedLoopClosureMatching(Solo(), HipPoolMatcher(96), 0.5, max_block=8)
+    assert sh.step(torch.from_numpy(X[:4]).cuda(), [0, 1, 2, 3]) == []
+    assert sh.matcher.size == 4

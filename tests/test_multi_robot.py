@@ -1,0 +1,170 @@
+"""Multi-process (gloo, CPU) test of the robot-per-rank step protocol of
+cslam_amd/multi_robot.py.  The HIP pool cannot run here, so the oracle (CPU restatement of the
+search) is plugged in as the matcher: what is under test is the protocol — all-gather of ragged
+blocks, the two-phase match, the record exchange, identical replicas — against a sequential
+restatement of the reference's own semantics (cslam/loop_closure_sparse_matching.py:37-76)
+replayed in the order the protocol documents."""
+import os
+import pickle
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import knn as oracle_knn
+
+DIM = 48
+THR = 0.74
+MAXB = 5
+
+
+class OracleMatcher(object):
+    def __init__(self):
+        self.rows = np.zeros((0, DIM), np.float32)
+        self.keyframes = []
+
+    @property
+    def size(self):
+        return self.rows.shape[0]
+
+    def add_rows(self, block, keyframe_ids):
+        if block.shape[0]:
+            self.rows = np.vstack([self.rows, block.cpu().numpy()])
+            self.keyframes.extend(int(k) for k in keyframe_ids)
+
+    def search_best(self, queries, lo, hi):
+        m = queries.shape[0]
+        if m == 0 or hi <= lo:
+            return np.full(m, -1, np.int32), np.full(m, -np.inf, np.float32)
+        idx, sim, _ = oracle_knn.search(self.rows[lo:hi], queries.cpu().numpy(), 1)
+        return idx[:, 0] + lo, sim[:, 0]
+
+
+def make_blocks(world, steps, seed=0):
+    rs = np.random.RandomState(seed)
+    blocks = {}
+    next_kf = [0] * world
+    for t in range(steps):
+        for r in range(world):
+            b = int(rs.randint(0, MAXB + 1))  # ragged, sometimes empty
+            x = rs.rand(b, DIM).astype(np.float32)
+            kfs = list(range(next_kf[r], next_kf[r] + b))
+            next_kf[r] += b
+            blocks[(t, r)] = (x, kfs)
+    return blocks
+
+
+def _worker(rank, world, port, steps, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cslam_amd.multi_robot import ShardedLoopClosureMatching, TorchDistComm
+    blocks = make_blocks(world, steps)
+    sh = ShardedLoopClosureMatching(TorchDistComm(), OracleMatcher(), THR, max_block=MAXB)
+    produced = []
+    for t in range(steps):
+        x, kfs = blocks[(t, rank)]
+        produced.extend(tuple(e) for e in sh.step(torch.from_numpy(x), kfs))
+    cand = {k: float(v.weight) for k, v in sh.candidate_selector.candidate_edges.items()}
+    with open(f"{out_path}.{rank}", "wb") as f:
+        pickle.dump(dict(cand=cand, produced=produced, nb_poses=dict(sh.candidate_selector.nb_poses),
+                         pool=sh.matcher.size, bytes=sh.bytes_gathered), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def sequential_reference(world, steps):
+    """The reference's semantics with mirrored pools, replayed in protocol order: per step,
+    (1) every robot receives everybody's new descriptors — add to the mirror, best match in
+    the LOCAL pool (lcsm.py:58-76); (2) every robot inserts its own — add to the local pool,
+    best match in every MIRROR (lcsm.py:37-56)."""
+    from cslam_amd.algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
+                                                               EdgeInterRobot)
+    blocks = make_blocks(world, steps)
+    local = [OracleMatcher() for _ in range(world)]
+    mirror = [[OracleMatcher() for _ in range(world)] for _ in range(world)]
+    sel = [AlgebraicConnectivityMaximization(r, world) for r in range(world)]
+
+    def best(m, x):
+        if m.size == 0:
+            return None, None
+        idx, sim = m.search_best(torch.from_numpy(x[None, :]), 0, m.size)
+        return m.keyframes[int(idx[0])], float(sim[0])
+
+    for t in range(steps):
+        for r in range(world):                      # (1) deliveries, rank order
+            x, kfs = blocks[(t, r)]
+            for s in range(world):
+                if s == r:
+                    continue
+                for i, kf in enumerate(kfs):
+                    mirror[s][r].add_rows(torch.from_numpy(x[i:i + 1]), [kf])
+                    kb, sim = best(local[s], x[i])
+                    if kb is not None and sim >= THR:
+                        sel[s].add_match(EdgeInterRobot(s, kb, r, kf, sim))
+        for r in range(world):                      # (2) own insertions
+            x, kfs = blocks[(t, r)]
+            for i, kf in enumerate(kfs):
+                local[r].add_rows(torch.from_numpy(x[i:i + 1]), [kf])
+                for s in range(world):
+                    if s == r:
+                        continue
+                    kb, sim = best(mirror[r][s], x[i])
+                    if kb is not None and sim >= THR:
+                        sel[r].add_match(EdgeInterRobot(r, kf, s, kb, sim))
+    union = {}
+    for r in range(world):
+        for k, e in sel[r].candidate_edges.items():
+            union[k] = max(union.get(k, -1.0), float(e.weight))
+    return union, [m.size for m in local]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_protocol_matches_sequential_reference(world):
+    steps = 12
+    oracle_knn.lib()  # build the oracle before forking workers
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res")
+        mp.spawn(_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+        res = [pickle.load(open(f"{out}.{r}", "rb")) for r in range(world)]
+    union, sizes = sequential_reference(world, steps)
+    assert len(union) > 10                      # the threshold lets a useful number through
+    for r in range(world):
+        assert res[r]["pool"] == sizes[r]
+        assert set(res[r]["cand"]) == set(union), f"rank {r} replica differs from the reference union"
+        for k in union:
+            assert abs(res[r]["cand"][k] - union[k]) <= 1e-7
+        assert res[r]["cand"] == res[0]["cand"]  # replicas are identical
+        assert res[r]["nb_poses"] == res[0]["nb_poses"]
+    # every record was produced by exactly one rank, and no pool ever left its rank:
+    # gathered bytes per rank per step = R blocks + R metas + R record buffers
+    per_step = world * (MAXB * DIM * 4 + (MAXB + 1) * 8) + world * (2 * MAXB * (world - 1) + 1) * 5 * 8
+    assert all(res[r]["bytes"] == steps * per_step for r in range(world))
+
+
+def test_single_rank_degenerates_to_local_insert():
+    from cslam_amd.multi_robot import ShardedLoopClosureMatching
+
+    class Solo:
+        torch = torch
+        rank, world = 0, 1
+
+        def all_gather(self, t):
+            return t.unsqueeze(0)
+
+    sh = ShardedLoopClosureMatching(Solo(), OracleMatcher(), THR, max_block=MAXB)
+    x = np.random.RandomState(0).rand(3, DIM).astype(np.float32)
+    assert sh.step(torch.from_numpy(x), [0, 1, 2]) == []
+    assert sh.matcher.size == 3 and sh.is_broker()
