@@ -132,17 +132,32 @@ class MAC:
     def round_solution_tiebreaker(self, w, k, decimal_tol=10):
         """k largest by (round(w, decimal_tol), weight) (mac.py:168-189).
 
-        Evaluated with the very numpy call the reference makes so that exact ties (equal
-        rounded w AND equal weight — common when all candidate weights are 1) resolve to the
-        same edges as the reference; the structured array is built vectorised instead of by
-        a Python loop."""
-        w = np.asarray(w, dtype=np.float64)
-        keys = np.empty(len(w), dtype=[("w", "float"), ("weight", "float")])
-        keys["w"] = w.round(decimals=decimal_tol)
+        The selection runs in the native library (cslam_mac_round_tiebreak).  Only when the
+        k-th and (k+1)-th keys are EXACTLY equal — the outcome then depends on numpy's
+        introselect, e.g. when all candidate weights are 1 — is the very numpy call of the
+        reference evaluated instead, so ties resolve to the same edges as the reference."""
+        w = _lib.as_f64(w)
+        m = len(w)
+        if k <= 0 or m == 0:
+            return np.zeros(m)
+        if k >= m:
+            return np.ones(m)
+        rounded = np.empty(m, np.float64)
+        _lib.check(self._lib.cslam_mac_round_tiebreak(self._handle, _lib.ptr(w), int(k),
+                                                      int(decimal_tol), _lib.ptr(rounded)))
+        tw = w.round(decimals=decimal_tol)
+        sel = rounded > 0.5
+        lo_tw = tw[sel].min()
+        lo_wt = self.weights[sel & (tw == lo_tw)].min()
+        hi_tw = tw[~sel].max()
+        hi_wt = self.weights[~sel & (tw == hi_tw)].max()
+        if (lo_tw, lo_wt) != (hi_tw, hi_wt):
+            return rounded  # boundary is tie-free: the set is unique
+        keys = np.empty(m, dtype=[("w", "float"), ("weight", "float")])
+        keys["w"] = tw
         keys["weight"] = self.weights
-        rounded = np.zeros(len(w))
-        if k > 0:
-            rounded[np.argpartition(keys, -k, order=["w", "weight"])[-k:]] = 1.0
+        rounded = np.zeros(m)
+        rounded[np.argpartition(keys, -k, order=["w", "weight"])[-k:]] = 1.0
         return rounded
 
     def simple_random_round(self, w, k):
