@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
 //   a load in the epilogue would sit behind the ring's HBM loads (loads return in order).
 //   Requires nkb % U == 0 (the host picks U).
 // ---------------------------------------------------------------------------------------------
-template <int T, int S, int U>
+template <int T, int S, int U, int G = 1>
 __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64_t xs, int64_t n,
                                               int dp, const float* __restrict__ Q, int m_valid,
                                               float* __restrict__ dots, int64_t dots_stride,
@@ -286,13 +286,20 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
 #pragma unroll
         for (int s = 0; s < S; ++s) xn[s] = rowptr(ngrp, s) + (int64_t)nturn * U * 4;
         const int qn = nturn * U * 4;
+        // consume G slots, then refill those G slots (G = 2: the two 64-B halves of every
+        // 128-B line are requested back to back)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            mfma_slot(u);
+        for (int u0 = 0; u0 < U; u0 += G) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) a[u][s] = xn[s][u * 4];
+            for (int u = u0; u < u0 + G; ++u) mfma_slot(u);
 #pragma unroll
-            for (int t = 0; t < T; ++t) b[u][t] = qp[t][qn + u * 4];
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int u = u0; u < u0 + G; ++u) a[u][s] = xn[s][u * 4];
+#pragma unroll
+            for (int u = u0; u < u0 + G; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t) b[u][t] = qp[t][qn + u * 4];
         }
         if (nturn == 0 || nturn % fold_turns == 0) fold();
         if (nturn == 0) store_group(grp);
@@ -509,15 +516,22 @@ template <int T, int S, int U>
 void launch_scan_t(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
                    int64_t n_waves, hipStream_t st) {
     unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL((k_scan<T, S, U>), dim3(blocks), dim3(256), 0, st, p->rows + p->v0 * p->xs, p->xs, p->vn,
-                       p->dp, Q, m_valid, dots, dots_stride, n_waves);
+    // refill granularity of the register ring: G = U (consume the whole ring, then refill it in
+    // one burst) measured best for the HBM-bound T = 1 scan (profiles/r01_scan_sweep*.txt);
+    // the MFMA-bound T > 1 variants keep the rolling refill (G = 1).
+    constexpr int G = (T == 1) ? U : 1;
+    hipLaunchKernelGGL((k_scan<T, S, U, G>), dim3(blocks), dim3(256), 0, st,
+                       p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, m_valid, dots,
+                       dots_stride, n_waves);
 }
 
 template <int T, int S, int UMAX>
 void launch_scan_u(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
                    int64_t n_waves, hipStream_t st) {
     const int nkb = p->dp / 16;
-    if (UMAX >= 4 && nkb % 4 == 0)
+    if (UMAX >= 8 && nkb % 8 == 0)
+        launch_scan_t<T, S, (UMAX >= 8 ? 8 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
+    else if (UMAX >= 4 && nkb % 4 == 0)
         launch_scan_t<T, S, (UMAX >= 4 ? 4 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
     else if (UMAX >= 2 && nkb % 2 == 0)
         launch_scan_t<T, S, (UMAX >= 2 ? 2 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
@@ -530,23 +544,20 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
                 hipStream_t st) {
     static const int wpc_env = getenv("CSLAM_SCAN_WPC") ? atoi(getenv("CSLAM_SCAN_WPC")) : 0;
     static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
-    const int wpc = wpc_env > 0 ? wpc_env : 4;  // measured best at S=4 (profiles/r01_scan_sweep.txt)
-    const int S = s_env > 0 ? s_env : 4;
-    int64_t groups = (p->vn + 16 * S - 1) / (16 * S);
+    const int wpc = wpc_env > 0 ? wpc_env : 4;  // waves per CU (profiles/r01_scan_sweep*.txt)
+    const int S = s_env == 4 ? 4 : 8;  // strips sharing one query fragment (T = 1 path)
+    const int s_eff = (m <= 16) ? S : 4;
+    int64_t groups = (p->vn + 16 * s_eff - 1) / (16 * s_eff);
     int64_t resident = (int64_t)p->cus * wpc;
     int64_t n_waves = groups < resident ? groups : resident;
     if (n_waves < 1) n_waves = 1;
     bool prof = p->prof_on && p->prof_n < p->prof_max;
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
     if (m <= 16) {
-        if (S == 1)
-            launch_scan_u<1, 1, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
-        else if (S == 2)
-            launch_scan_u<1, 2, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
-        else if (S == 8)
-            launch_scan_u<1, 8, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
-        else
+        if (S == 4)
             launch_scan_u<1, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        else
+            launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
     } else if (m <= 32) {
         launch_scan_u<2, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
     } else {
