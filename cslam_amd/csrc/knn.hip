@@ -313,6 +313,132 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
     store_group(grp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_scan_lds<S,NW>: the HBM-bound scan (<= 16 queries) with LDS-staged query tiles.
+//   Block = NW waves that walk k in lockstep, one 512-float stage (= one fold chunk) at a time.
+//   The stage's query tile [16 cols][512 floats] is staged ONCE per block into LDS (double
+//   buffered, prefetched one stage ahead through registers) and shared by the NW waves: the
+//   L2 query stream drops to 1/(NW*S) of the X stream, so waves can be many (16 per CU) and
+//   narrow (S = 1..2 strips) — the shape that streams best (profiles/r01_bw_probe2.txt).
+//   Each wave: own byte-balanced row range, bursts of 8 k-blocks x S strips straight from HBM
+//   to VGPRs (predicated, no clamped duplicates), B fragment by ds_read_b128 (column pitch
+//   516 floats → conflict free), same MFMA order and chunk folds as k_scan → identical bits.
+//   One barrier per stage; no divisibility constraint on the dimension.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStageKb = kChunkKb;                 // 32 k-blocks = 512 floats per stage
+constexpr int kQPitch = kStageKb * 16 + 4;         // floats per query column in LDS
+
+template <int S, int NW>
+__global__ __launch_bounds__(NW * 64) void k_scan_lds(const float* __restrict__ X, int64_t xs,
+                                                      int64_t n, int dp,
+                                                      const float* __restrict__ Q, int m_valid,
+                                                      float* __restrict__ dots,
+                                                      int64_t dots_stride, int64_t n_waves,
+                                                      int ngroups) {
+    __shared__ __attribute__((aligned(16))) float qs[2][16 * kQPitch];
+    constexpr int NT = NW * 64;
+    constexpr int NQ = (16 * kStageKb * 4) / NT;   // float4 per thread per stage
+    constexpr int UB = 8;                          // k-blocks per burst
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int64_t w = (int64_t)blockIdx.x * NW + wave;
+    const int64_t lo = w < n_waves ? (w * n) / n_waves : 0;
+    const int64_t hi = w < n_waves ? ((w + 1) * n) / n_waves : 0;
+    const int nkb = dp >> 4;
+    const int nstage = (nkb + kStageKb - 1) / kStageKb;
+    const int total = ngroups * nstage;
+
+    f32x4 qreg[NQ];
+    auto load_q = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int f = tid + i * NT;            // float4 index inside the stage tile
+            const int c = f / (kStageKb * 4);
+            const int j = f % (kStageKb * 4);
+            const int k = st * (kStageKb * 16) + 4 * j;
+            qreg[i] = (k < dp) ? *reinterpret_cast<const f32x4*>(Q + (int64_t)c * dp + k)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int f = tid + i * NT;
+            const int c = f / (kStageKb * 4);
+            const int j = f % (kStageKb * 4);
+            *reinterpret_cast<f32x4*>(&qs[buf][c * kQPitch + 4 * j]) = qreg[i];
+        }
+    };
+    load_q(0);
+    store_q(0);
+    __syncthreads();
+
+    int gi = 0;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const f32x4* xp[S];
+        bool valid[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int64_t row = lo + (int64_t)grp * (16 * S) + 16 * s + r;
+            valid[s] = row < hi;
+            xp[s] = reinterpret_cast<const f32x4*>(X + (valid[s] ? row : 0) * xs + 4 * g);
+        }
+        f32x4 tot[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nstage; ++st, ++gi) {
+            const int buf = gi & 1;
+            const bool has_next = gi + 1 < total;
+            if (has_next) load_q(st + 1 == nstage ? 0 : st + 1);
+            f32x4 acc[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int kb_lo = st * kStageKb;
+            const int kb_hi = min(nkb, kb_lo + kStageKb);
+            const float* qrow = &qs[buf][r * kQPitch + 4 * g];
+            for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += UB) {
+                f32x4 a[UB][S];
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        a[u][s] = (valid[s] && kb0 + u < kb_hi) ? xp[s][(kb0 + u) * 4]
+                                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (kb0 + u < kb_hi) {
+                        const f32x4 b =
+                            *reinterpret_cast<const f32x4*>(qrow + (kb0 + u - kb_lo) * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int s = 0; s < S; ++s)
+                                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s][j], b[j],
+                                                                              acc[s], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) tot[s] = tot[s] + acc[s];
+            if (has_next) store_q(buf ^ 1);
+            __syncthreads();
+        }
+        if (r < m_valid) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t r0 = lo + (int64_t)grp * (16 * S) + 16 * s + 4 * g;
+                float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < hi) out[e] = tot[s][e];
+            }
+        }
+    }
+}
+
 // cosine scaling of raw dots in place: sims[q][i] = (dot * rnx[i]) * rnq[q]
 __global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t stride, int64_t n,
                                                const float* __restrict__ rnx,
@@ -554,7 +680,33 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     bool prof = p->prof_on && p->prof_n < p->prof_max;
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
     if (m <= 16) {
-        if (S == 4)
+        static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
+        // default: register-ring kernel (5.3 TB/s); "lds" selects the block-synchronous
+        // LDS-staged variant (4.5-4.9 TB/s measured: the per-stage barrier couples 8 waves'
+        // HBM latencies; kept for A/B runs, profiles/r01_scan_lds_vs_ring.txt)
+        const bool use_lds = kern_env && strcmp(kern_env, "lds") == 0;
+        if (use_lds) {
+            static const int ls_env = getenv("CSLAM_SCAN_LS") ? atoi(getenv("CSLAM_SCAN_LS")) : 0;
+            static const int bpc_env = getenv("CSLAM_SCAN_BPC") ? atoi(getenv("CSLAM_SCAN_BPC")) : 0;
+            const int LS = ls_env == 2 ? 2 : 1;
+            const int bpc = bpc_env > 0 ? bpc_env : 2;
+            constexpr int NW = 8;
+            int64_t strips = (p->vn + 15) / 16;
+            int64_t blocks = (strips + NW - 1) / NW;
+            if (blocks > (int64_t)p->cus * bpc) blocks = (int64_t)p->cus * bpc;
+            if (blocks < 1) blocks = 1;
+            const int64_t nw = blocks * NW < p->vn ? blocks * NW : (p->vn > 0 ? p->vn : 1);
+            const int64_t rows_max = (p->vn + nw - 1) / nw;
+            const int ngroups = (int)((rows_max + 16 * LS - 1) / (16 * LS));
+            if (LS == 2)
+                hipLaunchKernelGGL((k_scan_lds<2, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
+                                   p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
+                                   dots_stride, nw, ngroups);
+            else
+                hipLaunchKernelGGL((k_scan_lds<1, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
+                                   p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
+                                   dots_stride, nw, ngroups);
+        } else if (S == 4)
             launch_scan_u<1, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
         else
             launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
