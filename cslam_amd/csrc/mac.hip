@@ -254,122 +254,166 @@ __device__ inline Aff compose(Aff first, Aff then) {  // apply `first`, then `th
     return Aff{then.m * first.m, then.m * first.c + then.c};
 }
 
-// inclusive scan of one Aff per thread across the 256-thread block
-__device__ inline Aff block_scan_aff(Aff v, Aff* smem /* [256] */) {
-    const int tid = threadIdx.x;
-    smem[tid] = v;
+// inclusive scan of one Aff per scan position across the 256-thread block; `pos` is the
+// thread's position in scan order (tid for the forward sweep, 255 - tid for the backward one)
+__device__ inline Aff block_scan_aff(Aff v, Aff* smem /* [256] */, int pos) {
+    smem[pos] = v;
     __syncthreads();
 #pragma unroll
     for (int off = 1; off < kScanThreads; off <<= 1) {
-        Aff o = smem[tid >= off ? tid - off : 0];
+        Aff o = smem[pos >= off ? pos - off : 0];
         __syncthreads();
-        if (tid >= off) v = compose(o, v);
-        smem[tid] = v;
+        if (pos >= off) v = compose(o, v);
+        smem[pos] = v;
         __syncthreads();
     }
     return v;
 }
 
-// element coefficients of the two sweeps
-//   forward  (DIR=0): y_i = r_i - l_{i-1} y_{i-1}            element j = i
-//   backward (DIR=1): z_i = y_i*invd_i - l_i z_{i+1}          element j = n-1-i
-template <int DIR>
-__device__ inline Aff elem(int j, int n, const double* __restrict__ rhs,
-                           const double* __restrict__ l, const double* __restrict__ invd) {
-    if (DIR == 0) {
-        return Aff{j > 0 ? -l[j - 1] : 0.0, rhs[j]};
-    } else {
-        int i = n - 1 - j;
-        return Aff{i + 1 < n ? -l[i] : 0.0, rhs[i] * invd[i]};
-    }
+// M z = r with M = L D L^T (unit lower bidiagonal L):
+//   forward   y_i = r_i - l_{i-1} y_{i-1}               (i ascending)
+//   backward  z_i = y_i * invd_i - l_i z_{i+1}          (i descending)
+// Both sweeps use the SAME partition (block b owns nodes [1024 b, 1024 b + 1024), thread t four
+// consecutive nodes), so the forward apply can emit the backward block composites from the y
+// values it still holds in registers: 3 launches per solve instead of 4.
+__device__ inline Aff fwd_elem(int i, const double* __restrict__ r, const double* __restrict__ l) {
+    return Aff{i > 0 ? -l[i - 1] : 0.0, r[i]};
 }
 
-// phase A: composite of every 1024-element block
-template <int DIR>
-__global__ __launch_bounds__(kScanThreads) void k_scan_agg(const double* __restrict__ rhs,
-                                                           const double* __restrict__ l,
-                                                           const double* __restrict__ invd, int n,
-                                                           Aff* __restrict__ agg,
-                                                           const Scalars* sc) {
+// (1) forward block composites
+__global__ __launch_bounds__(kScanThreads) void k_fwd_agg(const double* __restrict__ r,
+                                                          const double* __restrict__ l, int n,
+                                                          Aff* __restrict__ agg_f,
+                                                          const Scalars* sc) {
     if (sc->done) return;
     __shared__ Aff smem[kScanThreads];
-    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
+    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
     Aff t{1.0, 0.0};
 #pragma unroll
     for (int e = 0; e < kScanElems; ++e)
-        if (j0 + e < n) t = compose(t, elem<DIR>(j0 + e, n, rhs, l, invd));
-    Aff inc = block_scan_aff(t, smem);
-    if (threadIdx.x == kScanThreads - 1) agg[blockIdx.x] = inc;
+        if (i0 + e < n) t = compose(t, fwd_elem(i0 + e, r, l));
+    Aff inc = block_scan_aff(t, smem, threadIdx.x);
+    if (threadIdx.x == kScanThreads - 1) agg_f[blockIdx.x] = inc;
 }
 
-// phase B: prefix over preceding block composites, then the block's own elements.
-// DIR=0 writes y; DIR=1 writes z and per-block partial sums of z (for the mean).
-template <int DIR>
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const double* __restrict__ rhs,
-                                                             const double* __restrict__ l,
-                                                             const double* __restrict__ invd,
-                                                             int n, const Aff* __restrict__ agg,
-                                                             double* __restrict__ out,
-                                                             double* __restrict__ psum,
-                                                             const Scalars* sc) {
+// value entering a block: the composites of the blocks before it (in sweep order) applied to 0,
+// staged through LDS 256 at a time (a dependent chain of global loads by one lane costs
+// ~0.5 us per link).  first/step/count describe the sweep order over block ids.
+__device__ inline double incoming_value(const Aff* __restrict__ agg, int first, int step, int count,
+                                        Aff* smem, double* slot) {
+    double v = 0.0;
+    for (int c0 = 0; c0 < count; c0 += kScanThreads) {
+        const int cnt = min(kScanThreads, count - c0);
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) smem[threadIdx.x] = agg[first + step * (c0 + (int)threadIdx.x)];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int b = 0; b < cnt; ++b) v = smem[b].m * v + smem[b].c;
+    }
+    if (threadIdx.x == 0) *slot = v;
+    __syncthreads();
+    return *slot;
+}
+
+// (2) forward apply (writes y) + backward block composites
+__global__ __launch_bounds__(kScanThreads) void k_fwd_apply_bwd_agg(
+    const double* __restrict__ r, const double* __restrict__ l, const double* __restrict__ invd,
+    int n, const Aff* __restrict__ agg_f, double* __restrict__ y, Aff* __restrict__ agg_b,
+    const Scalars* sc) {
     if (sc->done) return;
     __shared__ Aff smem[kScanThreads];
-    __shared__ double red[4];
     __shared__ double vin_s;
-    // value entering this block = preceding block composites applied in order to 0; the
-    // composites are staged through LDS 256 at a time (a dependent chain of global loads by
-    // one lane costs ~0.5 us per link)
-    {
-        double v = 0.0;
-        for (int b0 = 0; b0 < (int)blockIdx.x; b0 += kScanThreads) {
-            const int cnt = min(kScanThreads, (int)blockIdx.x - b0);
-            __syncthreads();
-            if ((int)threadIdx.x < cnt) smem[threadIdx.x] = agg[b0 + threadIdx.x];
-            __syncthreads();
-            if (threadIdx.x == 0)
-                for (int b = 0; b < cnt; ++b) v = smem[b].m * v + smem[b].c;
-        }
-        if (threadIdx.x == 0) vin_s = v;
-        __syncthreads();
-    }
-    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
+    const double vin = incoming_value(agg_f, 0, 1, (int)blockIdx.x, smem, &vin_s);
+    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
     Aff el[kScanElems];
     Aff t{1.0, 0.0};
 #pragma unroll
     for (int e = 0; e < kScanElems; ++e) {
-        el[e] = (j0 + e < n) ? elem<DIR>(j0 + e, n, rhs, l, invd) : Aff{1.0, 0.0};
+        el[e] = (i0 + e < n) ? fwd_elem(i0 + e, r, l) : Aff{1.0, 0.0};
         t = compose(t, el[e]);
     }
-    Aff inc = block_scan_aff(t, smem);  // contains __syncthreads → vin_s visible
-    // exclusive prefix of this thread
-    Aff exc = threadIdx.x > 0 ? smem[threadIdx.x - 1] : Aff{1.0, 0.0};
-    (void)inc;
-    double v = exc.m * vin_s + exc.c;
-    double local = 0.0;
+    (void)block_scan_aff(t, smem, threadIdx.x);
+    const Aff exc = threadIdx.x > 0 ? smem[threadIdx.x - 1] : Aff{1.0, 0.0};
+    double v = exc.m * vin + exc.c;
+    double yv[kScanElems];
 #pragma unroll
     for (int e = 0; e < kScanElems; ++e) {
-        if (j0 + e < n) {
+        yv[e] = 0.0;
+        if (i0 + e < n) {
             v = el[e].m * v + el[e].c;
-            const int idx = (DIR == 0) ? (j0 + e) : (n - 1 - (j0 + e));
-            out[idx] = v;
+            yv[e] = v;
+            y[i0 + e] = v;
+        }
+    }
+    // backward composite of this thread's nodes, visited i0+3 → i0
+    Aff tb{1.0, 0.0};
+#pragma unroll
+    for (int e = kScanElems - 1; e >= 0; --e) {
+        const int i = i0 + e;
+        if (i < n) tb = compose(tb, Aff{i + 1 < n ? -l[i] : 0.0, yv[e] * invd[i]});
+    }
+    __syncthreads();
+    Aff incb = block_scan_aff(tb, smem, kScanThreads - 1 - (int)threadIdx.x);
+    if (threadIdx.x == 0) agg_b[blockIdx.x] = incb;
+}
+
+// (3) backward apply (writes z and per-block partial sums of z for the mean)
+__global__ __launch_bounds__(kScanThreads) void k_bwd_apply(const double* __restrict__ y,
+                                                            const double* __restrict__ l,
+                                                            const double* __restrict__ invd, int n,
+                                                            const Aff* __restrict__ agg_b,
+                                                            double* __restrict__ z,
+                                                            double* __restrict__ psum,
+                                                            const Scalars* sc) {
+    if (sc->done) return;
+    __shared__ Aff smem[kScanThreads];
+    __shared__ double red[4];
+    __shared__ double vin_s;
+    const int nb = gridDim.x;
+    const double vin = incoming_value(agg_b, nb - 1, -1, nb - 1 - (int)blockIdx.x, smem, &vin_s);
+    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
+    Aff el[kScanElems];
+    Aff tb{1.0, 0.0};
+#pragma unroll
+    for (int e = kScanElems - 1; e >= 0; --e) {
+        const int i = i0 + e;
+        el[e] = (i < n) ? Aff{i + 1 < n ? -l[i] : 0.0, y[i] * invd[i]} : Aff{1.0, 0.0};
+        tb = compose(tb, el[e]);
+    }
+    const int pos = kScanThreads - 1 - (int)threadIdx.x;
+    (void)block_scan_aff(tb, smem, pos);
+    const Aff exc = pos > 0 ? smem[pos - 1] : Aff{1.0, 0.0};
+    double v = exc.m * vin + exc.c;
+    double local = 0.0;
+#pragma unroll
+    for (int e = kScanElems - 1; e >= 0; --e) {
+        const int i = i0 + e;
+        if (i < n) {
+            v = el[e].m * v + el[e].c;
+            z[i] = v;
             local += v;
         }
     }
-    (void)red;
-    if (DIR == 1) {
-        double s[1] = {local};
-        block_sum<1>(s, red);
-        if (threadIdx.x == 0) psum[blockIdx.x] = s[0];
-    }
+    double sm[1] = {local};
+    block_sum<1>(sm, red);
+    if (threadIdx.x == 0) psum[blockIdx.x] = sm[0];
 }
 
 // --------------------------------------------------------------------------------------------
 // y = L x   (one thread per row; the working set lives in L2)
 // --------------------------------------------------------------------------------------------
+// aw[slot] = ew[adj_eid[slot]]: edge weights gathered once per solve into adjacency order, so
+// the mat-vec reads (nbr, weight) pairs contiguously instead of chasing edge ids
+__global__ __launch_bounds__(256) void k_adj_weights(const int32_t* __restrict__ adj_eid,
+                                                     const double* __restrict__ ew, int64_t nslot,
+                                                     double* __restrict__ aw) {
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < nslot) aw[e] = ew[adj_eid[e]];
+}
+
 __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_ptr,
                                               const int32_t* __restrict__ adj_nbr,
-                                              const int32_t* __restrict__ adj_eid,
-                                              const double* __restrict__ ew,
+                                              const double* __restrict__ aw,
                                               const double* __restrict__ x,
                                               double* __restrict__ y, int n, const Scalars* sc) {
     if (sc->done) return;
@@ -377,8 +421,7 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_pt
     if (i >= n) return;
     const double xi = x[i];
     double acc = 0.0;
-    for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e)
-        acc += ew[adj_eid[e]] * (xi - x[adj_nbr[e]]);
+    for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) acc += aw[e] * (xi - x[adj_nbr[e]]);
     y[i] = acc;
 }
 
@@ -434,53 +477,269 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
 }
 
 // --------------------------------------------------------------------------------------------
-// 3x3 Rayleigh-Ritz (one thread): smallest eigenpair of  GA c = theta GB c  on the active basis
+// 3x3 Rayleigh-Ritz (one thread): smallest eigenpair of  GA c = theta GB c  on the active basis.
+// Everything is templated on the basis size K and the basis members so that every array index
+// is a compile-time constant: runtime-indexed locals go to scratch memory and made this kernel
+// 24 us (608 B of scratch per lane); in registers it is a few us.
 // --------------------------------------------------------------------------------------------
-__device__ inline void jacobi_smallest(int k, double A[3][3], double* theta, double u[3]) {
+template <int K>
+__device__ inline void sym_matvec(const double (&C)[3][3], const double (&v)[3], double (&o)[3]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) t += C[i][j] * v[j];
+        o[i] = t;
+    }
+}
+
+// y = adj(C - th I) v : the adjugate needs no pivoting and, when th is (nearly) an eigenvalue,
+// is (nearly) the rank-one projector onto its eigenvector — exactly the inverse-iteration step,
+// without the division.
+template <int K>
+__device__ inline void adj_apply(const double (&C)[3][3], double th, const double (&v)[3],
+                                 double (&y)[3]) {
+    if (K == 1) {
+        y[0] = v[0];
+    } else if (K == 2) {
+        const double m00 = C[0][0] - th, m11 = C[1][1] - th, m01 = C[0][1];
+        y[0] = m11 * v[0] - m01 * v[1];
+        y[1] = -m01 * v[0] + m00 * v[1];
+    } else {
+        const double m00 = C[0][0] - th, m11 = C[1][1] - th, m22 = C[2][2] - th;
+        const double m01 = C[0][1], m02 = C[0][2], m12 = C[1][2];
+        const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22,
+                     c02 = m01 * m12 - m02 * m11, c11 = m00 * m22 - m02 * m02,
+                     c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+        y[0] = c00 * v[0] + c01 * v[1] + c02 * v[2];
+        y[1] = c01 * v[0] + c11 * v[1] + c12 * v[2];
+        y[2] = c02 * v[0] + c12 * v[1] + c22 * v[2];
+    }
+}
+
+// Rayleigh-quotient iteration from e_0 (x is the current Ritz vector, so C is nearly diagonal
+// with C_00 its smallest entry once LOBPCG is under way), certified by the residual and by the
+// inertia of C - (theta - delta) I (all pivots positive ⇒ nothing lies below theta).
+template <int K>
+__device__ inline bool rqi_smallest(const double (&C)[3][3], double& theta, double (&u)[3]) {
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) scale = fmax(scale, fabs(C[i][i]));
+    if (!(scale > 0.0)) return false;
+    double v[3] = {1.0, 0.0, 0.0};
+    double th = C[0][0];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        double y[3] = {0.0, 0.0, 0.0};
+        adj_apply<K>(C, th, v, y);
+        double nn = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) nn += y[i] * y[i];
+        if (!(nn > 0.0) || !(nn < 1e300)) break;  // exact hit (adj = 0) or overflow: keep v
+        const double rn = rsqrt(nn);
+#pragma unroll
+        for (int i = 0; i < K; ++i) v[i] = y[i] * rn;
+        double cv[3];
+        sym_matvec<K>(C, v, cv);
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) t += v[i] * cv[i];
+        th = t;
+    }
+    double cv[3];
+    sym_matvec<K>(C, v, cv);
+    double res = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) res += fabs(cv[i] - th * v[i]);
+    if (!(res <= 1e-12 * scale)) return false;
+    const double sh = th - 1e-9 * scale;
+    const double d0 = C[0][0] - sh;
+    if (!(d0 > 0.0)) return false;
+    if (K >= 2) {
+        const double l10 = C[1][0] / d0;
+        const double d1 = (C[1][1] - sh) - l10 * C[1][0];
+        if (!(d1 > 0.0)) return false;
+        if (K == 3) {
+            const double l20 = C[2][0] / d0;
+            const double m21 = C[2][1] - l20 * C[1][0];
+            const double d2 = (C[2][2] - sh) - l20 * C[2][0] - (m21 / d1) * m21;
+            if (!(d2 > 0.0)) return false;
+        }
+    }
+    theta = th;
+#pragma unroll
+    for (int i = 0; i < K; ++i) u[i] = v[i];
+    return true;
+}
+
+// cyclic Jacobi (fallback, e.g. the first LOBPCG iterations)
+template <int K>
+__device__ inline void jacobi_smallest(double (&A)[3][3], double& theta, double (&u)[3]) {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < k; ++i)
-            for (int j = i + 1; j < k; ++j) off += A[i][j] * A[i][j];
-        double dia = 0.0;
-        for (int i = 0; i < k; ++i) dia += A[i][i] * A[i][i];
-        if (off <= 1e-40 * dia || off == 0.0) break;
-        for (int pi = 0; pi < k; ++pi)
-            for (int qi = pi + 1; qi < k; ++qi) {
-                double apq = A[pi][qi];
-                if (apq == 0.0) continue;
-                double tau = (A[qi][qi] - A[pi][pi]) / (2.0 * apq);
-                double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                for (int r = 0; r < k; ++r) {
-                    double arp = A[r][pi], arq = A[r][qi];
-                    A[r][pi] = c * arp - s * arq;
-                    A[r][qi] = s * arp + c * arq;
-                }
-                for (int r = 0; r < k; ++r) {
-                    double apr = A[pi][r], aqr = A[qi][r];
-                    A[pi][r] = c * apr - s * aqr;
-                    A[qi][r] = s * apr + c * aqr;
-                }
-                for (int r = 0; r < k; ++r) {
-                    double vrp = V[r][pi], vrq = V[r][qi];
-                    V[r][pi] = c * vrp - s * vrq;
-                    V[r][qi] = s * vrp + c * vrq;
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            dia += A[i][i] * A[i][i];
+#pragma unroll
+            for (int j = i + 1; j < K; ++j) off += A[i][j] * A[i][j];
+        }
+        if (off <= 1e-30 * dia || off == 0.0) break;  // |a_ij| <= 1e-15 |a_ii|
+#pragma unroll
+        for (int pi = 0; pi < K; ++pi)
+#pragma unroll
+            for (int qi = pi + 1; qi < K; ++qi) {
+                const double apq = A[pi][qi];
+                if (apq != 0.0) {
+                    const double tau = (A[qi][qi] - A[pi][pi]) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = rsqrt(1.0 + t * t), s = t * c;
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        const double arp = A[r][pi], arq = A[r][qi];
+                        A[r][pi] = c * arp - s * arq;
+                        A[r][qi] = s * arp + c * arq;
+                    }
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        const double apr = A[pi][r], aqr = A[qi][r];
+                        A[pi][r] = c * apr - s * aqr;
+                        A[qi][r] = s * apr + c * aqr;
+                    }
+#pragma unroll
+                    for (int r = 0; r < K; ++r) {
+                        const double vrp = V[r][pi], vrq = V[r][qi];
+                        V[r][pi] = c * vrp - s * vrq;
+                        V[r][qi] = s * vrp + c * vrq;
+                    }
                 }
             }
     }
-    int best = 0;
-    for (int i = 1; i < k; ++i)
-        if (A[i][i] < A[best][best]) best = i;
-    *theta = A[best][best];
-    for (int i = 0; i < k; ++i) u[i] = V[i][best];
+    // smallest diagonal entry and its eigenvector, by selects (no runtime indexing)
+    double best = A[0][0];
+    double b0 = V[0][0], b1 = V[1][0], b2 = V[2][0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) {
+        const bool lt = A[i][i] < best;
+        best = lt ? A[i][i] : best;
+        b0 = lt ? V[0][i] : b0;
+        b1 = lt ? V[1][i] : b1;
+        b2 = lt ? V[2][i] : b2;
+    }
+    theta = best;
+    u[0] = b0;
+    u[1] = b1;
+    u[2] = b2;
+}
+
+// Rayleigh-Ritz on the basis {S_I0, S_I1, S_I2}[0..K).  false = Gram matrix numerically
+// singular (near-dependent basis): the caller retries with a smaller basis.
+template <int K, int I0, int I1, int I2>
+__device__ inline bool rr_try(const double (&GB)[3][3], const double (&GA)[3][3],
+                              double (&coef)[3], double& theta) {
+    constexpr int ix[3] = {I0, I1, I2};
+    double s[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < K; ++i) s[i] = rsqrt(GB[ix[i]][ix[i]]);
+    double B[3][3], A[3][3];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            B[i][j] = GB[ix[i]][ix[j]] * s[i] * s[j];
+            A[i][j] = GA[ix[i]][ix[j]] * s[i] * s[j];
+        }
+    // Cholesky B = Lc Lc^T with a pivot floor; rl = 1 / Lc_ii
+    double Lc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double rl[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double d = B[j][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) d -= Lc[j][t] * Lc[j][t];
+        if (!(d > 1e-12)) return false;
+        rl[j] = rsqrt(d);
+        Lc[j][j] = d * rl[j];
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            double v = B[i][j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) v -= Lc[i][t] * Lc[j][t];
+            Lc[i][j] = v * rl[j];
+        }
+    }
+    // C = Lc^-1 A Lc^-T
+    double T[3][3], C[3][3];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double v = A[i][c];
+#pragma unroll
+            for (int t = 0; t < i; ++t) v -= Lc[i][t] * T[t][c];
+            T[i][c] = v * rl[i];
+        }
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double v = T[r][i];
+#pragma unroll
+            for (int t = 0; t < i; ++t) v -= Lc[i][t] * C[r][t];
+            C[r][i] = v * rl[i];
+        }
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = i + 1; j < K; ++j) C[i][j] = C[j][i] = 0.5 * (C[i][j] + C[j][i]);
+    double u[3] = {0.0, 0.0, 0.0};
+    if (!rqi_smallest<K>(C, theta, u)) jacobi_smallest<K>(C, theta, u);
+    // c' = Lc^-T u, then undo the scaling
+    double cp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        double v = u[i];
+#pragma unroll
+        for (int t = i + 1; t < K; ++t) v -= Lc[t][i] * cp[t];
+        cp[i] = v * rl[i];
+    }
+    coef[0] = coef[1] = coef[2] = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) coef[ix[i]] = cp[i] * s[i];
+    return true;
 }
 
 __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ partial, int nblk,
-                           const double* __restrict__ psum, int nscan, int use_mu, int n,
-                           Scalars* sc) {
+                                                  const double* __restrict__ psum, int nscan,
+                                                  int use_mu, int n,
+                                                  const double* __restrict__ rpart, Scalars* sc) {
     if (sc->done) return;
     __shared__ double smem[12 * 4];
+    __shared__ int stop_s;
+    if (rpart) {
+        // convergence test of the PREVIOUS Ritz update (networkx criterion
+        // ||r||_1 / ||L||_inf < tol, algebraicconnectivity.py:243).  The kernels of this
+        // iteration that already ran only touched w / Aw / scratch, never x or theta.
+        double rv[1] = {0.0};
+        for (int b = threadIdx.x; b < nblk; b += 256) rv[0] += rpart[b];
+        block_sum<1>(rv, smem);
+        if (threadIdx.x == 0) {
+            const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
+            sc->lnorm = lnorm;
+            sc->res = rv[0] / lnorm;
+            sc->iters += 1;
+            int d = 0;
+            if (sc->res < sc->tol)
+                d = 1;
+            else if (sc->iters >= sc->max_iters)
+                d = 3;
+            if (!(sc->res == sc->res)) d = 2;  // NaN
+            sc->done = d;
+            stop_s = d;
+        }
+        __syncthreads();
+        if (stop_s) return;
+    }
     double g[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) g[i] = 0.0;
@@ -494,80 +753,23 @@ __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ par
     sc->mu = mu;
     const double GB[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
     const double GA[3][3] = {{g[6], g[7], g[8]}, {g[7], g[9], g[10]}, {g[8], g[10], g[11]}};
-    // active basis vectors: non-negligible norm relative to x
-    int idx[3];
-    int k = 0;
-    double s[3];
-    for (int i = 0; i < 3; ++i) {
-        if (GB[i][i] > 1e-280 && (i == 0 || GB[i][i] > 1e-60 * GB[0][0])) {
-            idx[k] = i;
-            s[k] = 1.0 / sqrt(GB[i][i]);
-            ++k;
-        }
-    }
-    double coef[3] = {0.0, 0.0, 0.0};
-    double theta = sc->theta;
-    if (k == 0 || idx[0] != 0) {  // x vanished: breakdown
+    if (!(GB[0][0] > 1e-280)) {  // x vanished: breakdown
         sc->done = 2;
         return;
     }
-    while (k >= 1) {
-        double B[3][3], A[3][3];
-        for (int i = 0; i < k; ++i)
-            for (int j = 0; j < k; ++j) {
-                B[i][j] = GB[idx[i]][idx[j]] * s[i] * s[j];
-                A[i][j] = GA[idx[i]][idx[j]] * s[i] * s[j];
-            }
-        // Cholesky B = Lc Lc^T with a pivot floor: near-dependent basis → drop the last vector
-        double Lc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        bool ok = true;
-        for (int j = 0; j < k && ok; ++j) {
-            double dsum = B[j][j];
-            for (int t = 0; t < j; ++t) dsum -= Lc[j][t] * Lc[j][t];
-            if (!(dsum > 1e-12)) {
-                ok = false;
-                break;
-            }
-            Lc[j][j] = sqrt(dsum);
-            for (int i = j + 1; i < k; ++i) {
-                double v = B[i][j];
-                for (int t = 0; t < j; ++t) v -= Lc[i][t] * Lc[j][t];
-                Lc[i][j] = v / Lc[j][j];
-            }
-        }
-        if (!ok) {
-            --k;
-            continue;
-        }
-        // C = Lc^-1 A Lc^-T
-        double T[3][3], C[3][3];
-        for (int c = 0; c < k; ++c) {  // solve Lc * T[:,c] = A[:,c]
-            for (int i = 0; i < k; ++i) {
-                double v = A[i][c];
-                for (int t = 0; t < i; ++t) v -= Lc[i][t] * T[t][c];
-                T[i][c] = v / Lc[i][i];
-            }
-        }
-        for (int r = 0; r < k; ++r) {  // C[r,:] : solve Lc * C[r,:]^T = T[r,:]^T
-            for (int i = 0; i < k; ++i) {
-                double v = T[r][i];
-                for (int t = 0; t < i; ++t) v -= Lc[i][t] * C[r][t];
-                C[r][i] = v / Lc[i][i];
-            }
-        }
-        for (int i = 0; i < k; ++i)
-            for (int j = i + 1; j < k; ++j) C[i][j] = C[j][i] = 0.5 * (C[i][j] + C[j][i]);
-        double u[3];
-        jacobi_smallest(k, C, &theta, u);
-        // c' = Lc^-T u
-        double cp[3];
-        for (int i = k - 1; i >= 0; --i) {
-            double v = u[i];
-            for (int t = i + 1; t < k; ++t) v -= Lc[t][i] * cp[t];
-            cp[i] = v / Lc[i][i];
-        }
-        for (int i = 0; i < k; ++i) coef[idx[i]] = cp[i] * s[i];
-        break;
+    // basis members with a non-negligible norm relative to x
+    const bool has_w = GB[1][1] > 1e-280 && GB[1][1] > 1e-60 * GB[0][0];
+    const bool has_p = GB[2][2] > 1e-280 && GB[2][2] > 1e-60 * GB[0][0];
+    double coef[3] = {0.0, 0.0, 0.0};
+    double theta = sc->theta;
+    bool ok = false;
+    if (has_w && has_p) ok = rr_try<3, 0, 1, 2>(GB, GA, coef, theta);
+    if (!ok && has_w) ok = rr_try<2, 0, 1, 2>(GB, GA, coef, theta);   // p dropped (restart)
+    if (!ok && has_p && !has_w) ok = rr_try<2, 0, 2, 1>(GB, GA, coef, theta);
+    if (!ok) ok = rr_try<1, 0, 1, 2>(GB, GA, coef, theta);
+    if (!ok) {
+        sc->done = 2;
+        return;
     }
     if (coef[0] < 0.0) {  // keep the orientation of x
         coef[0] = -coef[0];
@@ -609,24 +811,21 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ x, const do
     if (threadIdx.x == 0) rpart[blockIdx.x] = v[0];
 }
 
-__global__ __launch_bounds__(256) void k_check(const double* __restrict__ rpart, int nblk,
-                                               Scalars* sc) {
+// end-of-replay convergence word for the host (same test k_rr_solve makes at the start of the
+// next iteration; does not count an iteration)
+__global__ __launch_bounds__(256) void k_final_check(const double* __restrict__ rpart, int nblk,
+                                                     Scalars* sc) {
     if (sc->done) return;
     __shared__ double smem[4];
     double v[1] = {0.0};
     for (int b = threadIdx.x; b < nblk; b += 256) v[0] += rpart[b];
     block_sum<1>(v, smem);
     if (threadIdx.x != 0) return;
-    const double s = v[0];
-    double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
+    const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
     sc->lnorm = lnorm;
-    sc->res = s / lnorm;
-    sc->iters += 1;
-    if (sc->res < sc->tol)
-        sc->done = 1;
-    else if (sc->iters >= sc->max_iters)
-        sc->done = 3;
-    if (!(sc->res == sc->res)) sc->done = 2;  // NaN
+    sc->res = v[0] / lnorm;
+    if (sc->res < sc->tol) sc->done = 1;
+    if (!(sc->res == sc->res)) sc->done = 2;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -724,6 +923,140 @@ __global__ __launch_bounds__(1024) void k_topk_mask(const double* __restrict__ x
     }
 }
 
+// ---- multi-block top-k mask: 3 levels of 11-bit histograms narrow the k-th value down to the
+// elements that share its top 33 key bits (for continuous data: a handful; exact ties: all of
+// them), which one block then orders by (value desc, index asc).  8 small launches instead of
+// one 1024-thread block sweeping the array 9 times (635 us → ~25 us at m = 200k).
+constexpr int kTopkBins = 2048;
+constexpr int kTopkListCap = 4096;
+struct TopkState {
+    unsigned long long prefix;  // top 11*level key bits of the k-th largest value
+    long long krem;             // how many entries of the threshold bin are still to be taken
+    unsigned int list_count;
+    int overflow;               // threshold bin larger than kTopkListCap → caller falls back
+};
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_topk_hist(const double* __restrict__ x, int64_t m,
+                                                   const TopkState* __restrict__ stt,
+                                                   unsigned int* __restrict__ hist) {
+    __shared__ unsigned int lh[kTopkBins];
+    for (int b = threadIdx.x; b < kTopkBins; b += 256) lh[b] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = stt->prefix;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = d2ord(x[i]);
+        if (LEVEL == 0 || (key >> (64 - 11 * LEVEL)) == prefix)
+            atomicAdd(&lh[(key >> (64 - 11 * (LEVEL + 1))) & (kTopkBins - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kTopkBins; b += 256)
+        if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+
+// one block: walk the histogram from the top bin down, extend the prefix, clear the histogram
+__global__ __launch_bounds__(256) void k_topk_pick(unsigned int* __restrict__ hist, int64_t k,
+                                                   int first, TopkState* __restrict__ stt) {
+    __shared__ unsigned int lh[kTopkBins];
+    for (int b = threadIdx.x; b < kTopkBins; b += 256) {
+        lh[b] = hist[b];
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    // each thread sums its 8 consecutive bins; thread 0 walks the 256 chunk sums from the top,
+    // then the 8 bins inside the chunk that holds the k-th value
+    __shared__ unsigned int csum[256];
+    {
+        unsigned int t = 0;
+        for (int b = 0; b < 8; ++b) t += lh[threadIdx.x * 8 + b];
+        csum[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long krem = first ? (long long)k : stt->krem;
+        int ch = 255;
+        for (; ch > 0; --ch) {
+            if ((long long)csum[ch] >= krem) break;
+            krem -= csum[ch];
+        }
+        int bin = ch * 8 + 7;
+        for (; bin > ch * 8; --bin) {
+            if ((long long)lh[bin] >= krem) break;
+            krem -= lh[bin];
+        }
+        stt->prefix = first ? (unsigned long long)bin : ((stt->prefix << 11) | (unsigned long long)bin);
+        stt->krem = krem;
+        stt->list_count = 0u;
+        stt->overflow = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_topk_scatter(const double* __restrict__ x, int64_t m,
+                                                      TopkState* __restrict__ stt,
+                                                      double* __restrict__ mask,
+                                                      unsigned long long* __restrict__ lkey,
+                                                      unsigned int* __restrict__ lidx) {
+    const unsigned long long prefix = stt->prefix;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = d2ord(x[i]);
+        const unsigned long long top = key >> 31;
+        if (top > prefix) {
+            mask[i] = 1.0;
+        } else if (top < prefix) {
+            mask[i] = 0.0;
+        } else {
+            unsigned int pos = atomicAdd(&stt->list_count, 1u);
+            if (pos < (unsigned)kTopkListCap) {
+                lkey[pos] = key;
+                lidx[pos] = (unsigned int)i;
+            }
+            mask[i] = 0.0;
+        }
+    }
+}
+
+// one block: order the threshold-bin entries by (key desc, index asc), keep the first krem
+__global__ __launch_bounds__(1024) void k_topk_finish(TopkState* __restrict__ stt,
+                                                      double* __restrict__ mask,
+                                                      const unsigned long long* __restrict__ lkey,
+                                                      const unsigned int* __restrict__ lidx) {
+    __shared__ unsigned long long sk[kTopkListCap];
+    __shared__ unsigned int si[kTopkListCap];
+    const unsigned int c = stt->list_count;
+    if (c > (unsigned)kTopkListCap) {
+        if (threadIdx.x == 0) stt->overflow = 1;
+        return;
+    }
+    unsigned int np2 = 1;
+    while (np2 < c) np2 <<= 1;
+    for (unsigned int i = threadIdx.x; i < np2; i += 1024) {
+        sk[i] = i < c ? lkey[i] : 0ull;            // padding sorts last (key 0 < any real key...
+        si[i] = i < c ? lidx[i] : 0xFFFFFFFFu;     // ...and the largest index on key ties)
+    }
+    __syncthreads();
+    for (unsigned int size = 2; size <= np2; size <<= 1) {
+        for (unsigned int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned int t = threadIdx.x; t < np2 / 2; t += 1024) {
+                unsigned int pos = 2 * t - (t & (stride - 1));
+                unsigned long long ka = sk[pos], kb = sk[pos + stride];
+                unsigned int ia = si[pos], ib = si[pos + stride];
+                bool a_first = (ka > kb) || (ka == kb && ia < ib);  // a belongs before b
+                bool desc = (pos & size) == 0;
+                if (desc ? !a_first : a_first) {
+                    sk[pos] = kb;
+                    sk[pos + stride] = ka;
+                    si[pos] = ib;
+                    si[pos + stride] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const long long krem = stt->krem;
+    for (unsigned int i = threadIdx.x; i < c; i += 1024)
+        if ((long long)i < krem) mask[si[i]] = 1.0;
+}
+
 // u = min(u, f + g.(s - w)); gap test (mac.py:219-225)
 __global__ __launch_bounds__(1024) void k_fw_dual(const double* __restrict__ g,
                                                   const double* __restrict__ s,
@@ -772,7 +1105,8 @@ struct cslam_mac {
     // device
     int32_t *adj_ptr = nullptr, *adj_nbr = nullptr, *adj_eid = nullptr;
     int32_t *ci_d = nullptr, *cj_d = nullptr;
-    double *cw_d = nullptr, *ew = nullptr;
+    double *cw_d = nullptr, *ew = nullptr, *aw = nullptr;
+    int64_t nslot = 0;
     uint8_t* link = nullptr;
     double *a = nullptr, *b = nullptr, *l = nullptr, *invd = nullptr;
     double *x = nullptr, *w = nullptr, *p = nullptr, *Ax = nullptr, *Aw = nullptr, *Ap = nullptr,
@@ -783,6 +1117,10 @@ struct cslam_mac {
     double *psum = nullptr, *partial = nullptr, *rpart = nullptr;
     Scalars* sc = nullptr;
     double *wvec = nullptr, *gvec = nullptr, *svec = nullptr;  // FW state [m]
+    TopkState* tk_state = nullptr;
+    unsigned int* tk_hist = nullptr;
+    unsigned long long* tk_lkey = nullptr;
+    unsigned int* tk_lidx = nullptr;
     int nscan = 0, nred = 0;
     bool have_warm = false;
     hipGraphExec_t graph = nullptr;
@@ -832,29 +1170,46 @@ bool graph_connected(const cslam_mac* mac, const double* w, double tol) {
     return comps == 1;
 }
 
+// mask of the k largest entries of x (device pointers); async on st.  The caller must check
+// tk_state->overflow after a sync and re-run with k_topk_mask when set (massive exact ties).
+void launch_topk(const double* x, int64_t m, int64_t k, double* mask, TopkState* stt,
+                 unsigned int* hist, unsigned long long* lkey, unsigned int* lidx, hipStream_t st) {
+    if (k <= 0 || k >= m) {
+        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, st, x, m, k, mask);
+        return;
+    }
+    unsigned g = (unsigned)std::min<int64_t>((m + 255) / 256, 1024);
+    hipLaunchKernelGGL((k_topk_hist<0>), dim3(g), dim3(256), 0, st, x, m, stt, hist);
+    hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(256), 0, st, hist, k, 1, stt);
+    hipLaunchKernelGGL((k_topk_hist<1>), dim3(g), dim3(256), 0, st, x, m, stt, hist);
+    hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(256), 0, st, hist, k, 0, stt);
+    hipLaunchKernelGGL((k_topk_hist<2>), dim3(g), dim3(256), 0, st, x, m, stt, hist);
+    hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(256), 0, st, hist, k, 0, stt);
+    hipLaunchKernelGGL(k_topk_scatter, dim3(g), dim3(256), 0, st, x, m, stt, mask, lkey, lidx);
+    hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, st, stt, mask, lkey, lidx);
+}
+
 void launch_iteration(cslam_mac* mac, hipStream_t st) {
     const int n = mac->n;
     const unsigned gs = (unsigned)mac->nscan, gr = (unsigned)mac->nred;
     const unsigned gn = (unsigned)((n + 255) / 256);
-    // w = M^-1 r  (forward + backward affine scans), psum = per-block sums of w
-    hipLaunchKernelGGL((k_scan_agg<0>), dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
-                       mac->invd, n, mac->agg_f, mac->sc);
-    hipLaunchKernelGGL((k_scan_apply<0>), dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
-                       mac->invd, n, mac->agg_f, mac->y, mac->psum, mac->sc);
-    hipLaunchKernelGGL((k_scan_agg<1>), dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l,
-                       mac->invd, n, mac->agg_b, mac->sc);
-    hipLaunchKernelGGL((k_scan_apply<1>), dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l,
-                       mac->invd, n, mac->agg_b, mac->w, mac->psum, mac->sc);
+    // w = M^-1 r  (forward + backward affine scans, 3 launches), psum = per-block sums of w
+    hipLaunchKernelGGL(k_fwd_agg, dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l, n,
+                       mac->agg_f, mac->sc);
+    hipLaunchKernelGGL(k_fwd_apply_bwd_agg, dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
+                       mac->invd, n, mac->agg_f, mac->y, mac->agg_b, mac->sc);
+    hipLaunchKernelGGL(k_bwd_apply, dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l, mac->invd,
+                       n, mac->agg_b, mac->w, mac->psum, mac->sc);
     // Aw = L w
-    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr,
-                       mac->adj_eid, mac->ew, mac->w, mac->Aw, n, mac->sc);
+    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
+                       mac->w, mac->Aw, n, mac->sc);
     hipLaunchKernelGGL(k_dots, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax, mac->Aw,
                        mac->Ap, n, mac->psum, mac->nscan, 1, mac->partial, mac->sc);
+    // convergence test of the previous update + 3x3 Rayleigh-Ritz
     hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                       mac->nscan, 1, n, mac->sc);
+                       mac->nscan, 1, n, mac->rpart, mac->sc);
     hipLaunchKernelGGL(k_update, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax,
                        mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
 }
 
 int build_graph(cslam_mac* mac) {
@@ -862,6 +1217,8 @@ int build_graph(cslam_mac* mac) {
     hipGraph_t g = nullptr;
     CSLAM_HIP_TRY(hipStreamBeginCapture(mac->stream, hipStreamCaptureModeThreadLocal));
     for (int it = 0; it < kIterPerGraph; ++it) launch_iteration(mac, mac->stream);
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, mac->stream, mac->rpart, mac->nred,
+                       mac->sc);
     CSLAM_HIP_TRY(hipStreamEndCapture(mac->stream, &g));
     CSLAM_HIP_TRY(hipGraphInstantiate(&mac->graph, g, nullptr, nullptr, 0));
     CSLAM_HIP_TRY(hipGraphDestroy(g));
@@ -902,15 +1259,17 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
     CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
     CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
     CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
-    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr,
-                       mac->adj_eid, mac->ew, mac->x, mac->Ax, n, mac->sc);
+    hipLaunchKernelGGL(k_adj_weights, dim3((unsigned)((mac->nslot + 255) / 256)), dim3(256), 0, st,
+                       mac->adj_eid, mac->ew, mac->nslot, mac->aw);
+    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
+                       mac->x, mac->Ax, n, mac->sc);
     hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
                        mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
     hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                       mac->nscan, 0, n, mac->sc);
+                       mac->nscan, 0, n, (const double*)nullptr, mac->sc);
     hipLaunchKernelGGL(k_update, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
                        mac->Ax, mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
     CSLAM_HIP_TRY(hipGetLastError());
     CSLAM_TRY(build_graph(mac));
     Scalars h;
@@ -1057,6 +1416,8 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->cj_d, n_cand));
     A(dev_alloc(&mac->cw_d, n_cand));
     A(dev_alloc(&mac->ew, E));
+    mac->nslot = (int64_t)nbr.size();
+    A(dev_alloc(&mac->aw, nbr.size()));
     A(dev_alloc(&mac->link, n));
     for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
                        &mac->Aw, &mac->Ap, &mac->r, &mac->y})
@@ -1071,6 +1432,10 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->wvec, n_cand));
     A(dev_alloc(&mac->gvec, n_cand));
     A(dev_alloc(&mac->svec, n_cand));
+    A(dev_alloc(&mac->tk_state, 1));
+    A(dev_alloc(&mac->tk_hist, kTopkBins));
+    A(dev_alloc(&mac->tk_lkey, kTopkListCap));
+    A(dev_alloc(&mac->tk_lidx, kTopkListCap));
     if (rc != CSLAM_OK) {
         cslam_mac_destroy(mac);
         return rc;
@@ -1092,6 +1457,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     H2D(mac->x, x0.data(), (size_t)n * 8);
     if (rc == CSLAM_OK && (hipMemset(mac->sc, 0, sizeof(Scalars)) != hipSuccess ||
                            hipMemset(mac->l, 0, sizeof(double) * n) != hipSuccess ||
+                           hipMemset(mac->tk_hist, 0, sizeof(unsigned int) * kTopkBins) != hipSuccess ||
                            hipMemset(mac->b, 0, sizeof(double) * n) != hipSuccess ||
                            hipEventCreate(&mac->ev0) != hipSuccess ||
                            hipEventCreate(&mac->ev1) != hipSuccess))
@@ -1110,13 +1476,14 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
     if (mac->stream) (void)hipStreamSynchronize(mac->stream);
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
     for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
-                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->link,
+                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->link,
                     (void*)mac->a, (void*)mac->b,
                     (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
                     (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
                     (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->agg_m, (void*)mac->psum, (void*)mac->partial,
                     (void*)mac->rpart, (void*)mac->sc, (void*)mac->wvec, (void*)mac->gvec,
-                    (void*)mac->svec})
+                    (void*)mac->svec, (void*)mac->tk_state, (void*)mac->tk_hist, (void*)mac->tk_lkey,
+                    (void*)mac->tk_lidx})
         if (p) (void)hipFree(p);
     if (mac->ev0) (void)hipEventDestroy(mac->ev0);
     if (mac->ev1) (void)hipEventDestroy(mac->ev1);
@@ -1234,24 +1601,35 @@ int cslam_mac_grad(cslam_mac_t* mac, const double* v, double* g) {
 int cslam_topk_mask(const double* x, int64_t m, int64_t k, double* mask) {
     if (m < 0 || k < 0 || (m > 0 && (!x || !mask))) return fail(CSLAM_E_INVALID, "topk_mask: bad args");
     if (m == 0) return CSLAM_OK;
-    double *dx = nullptr, *dm = nullptr;
-    CSLAM_HIP_TRY(hipMalloc(&dx, m * 8));
-    hipError_t e = hipMalloc(&dm, m * 8);
-    if (e != hipSuccess) {
-        (void)hipFree(dx);
-        return fail(CSLAM_E_HIP, "topk_mask: hipMalloc: %s", hipGetErrorString(e));
+    struct Scratch {
+        double *dx = nullptr, *dm = nullptr;
+        TopkState* stt = nullptr;
+        unsigned int *hist = nullptr, *lidx = nullptr;
+        unsigned long long* lkey = nullptr;
+        ~Scratch() {
+            for (void* p : {(void*)dx, (void*)dm, (void*)stt, (void*)hist, (void*)lidx, (void*)lkey})
+                if (p) (void)hipFree(p);
+        }
+    } sc;
+    CSLAM_TRY(dev_alloc(&sc.dx, m));
+    CSLAM_TRY(dev_alloc(&sc.dm, m));
+    CSLAM_TRY(dev_alloc(&sc.stt, 1));
+    CSLAM_TRY(dev_alloc(&sc.hist, kTopkBins));
+    CSLAM_TRY(dev_alloc(&sc.lkey, kTopkListCap));
+    CSLAM_TRY(dev_alloc(&sc.lidx, kTopkListCap));
+    CSLAM_HIP_TRY(hipMemset(sc.hist, 0, sizeof(unsigned int) * kTopkBins));
+    CSLAM_HIP_TRY(hipMemset(sc.stt, 0, sizeof(TopkState)));
+    CSLAM_HIP_TRY(hipMemcpy(sc.dx, x, m * 8, hipMemcpyHostToDevice));
+    launch_topk(sc.dx, m, k, sc.dm, sc.stt, sc.hist, sc.lkey, sc.lidx, 0);
+    CSLAM_HIP_TRY(hipGetLastError());
+    TopkState ts;
+    CSLAM_HIP_TRY(hipMemcpy(&ts, sc.stt, sizeof(ts), hipMemcpyDeviceToHost));
+    if (k > 0 && k < m && ts.overflow) {
+        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, 0, sc.dx, m, k, sc.dm);
+        CSLAM_HIP_TRY(hipGetLastError());
     }
-    int rc = CSLAM_OK;
-    if (hipMemcpy(dx, x, m * 8, hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(CSLAM_E_HIP, "topk_mask: H2D failed");
-    if (rc == CSLAM_OK) {
-        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, 0, dx, m, k, dm);
-        if (hipGetLastError() != hipSuccess || hipMemcpy(mask, dm, m * 8, hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(CSLAM_E_HIP, "topk_mask: kernel/D2H failed");
-    }
-    (void)hipFree(dx);
-    (void)hipFree(dm);
-    return rc;
+    CSLAM_HIP_TRY(hipMemcpy(mask, sc.dm, m * 8, hipMemcpyDeviceToHost));
+    return CSLAM_OK;
 }
 
 // round_solution_tiebreaker (mac.py:168-189): k largest under the lexicographic key
@@ -1321,7 +1699,16 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
         }
         hipLaunchKernelGGL(k_grad, dim3(gm), dim3(256), 0, st, mac->ci_d, mac->cj_d, mac->cw_d,
                            mac->x, m, mac->gvec);
-        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, st, mac->gvec, m, k, mac->svec);
+        launch_topk(mac->gvec, m, k, mac->svec, mac->tk_state, mac->tk_hist, mac->tk_lkey,
+                    mac->tk_lidx, st);
+        {
+            TopkState ts;
+            CSLAM_HIP_TRY(hipMemcpyAsync(&ts, mac->tk_state, sizeof(ts), hipMemcpyDeviceToHost, st));
+            CSLAM_HIP_TRY(hipStreamSynchronize(st));
+            if (k > 0 && k < m && ts.overflow)  // > 4096 entries tie with the k-th value
+                hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, st, mac->gvec, m, k,
+                                   mac->svec);
+        }
         hipLaunchKernelGGL(k_fw_dual, dim3(1), dim3(1024), 0, st, mac->gvec, mac->svec, mac->wvec, m,
                            mac->sc);
         hipLaunchKernelGGL(k_fw_step, dim3(gm), dim3(256), 0, st, mac->wvec, mac->svec, m, mac->sc);

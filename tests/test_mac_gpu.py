@@ -91,6 +91,16 @@ def test_round_solution_and_topk(gpu):
         ref = np.zeros(m)
         ref[np.argsort(-x, kind="stable")[:k]] = 1.0
         np.testing.assert_array_equal(mask, ref)
+    x = np.round(rs.randn(30000), 1)                          # > 4096 exact ties at the k-th value
+    mask = mac.round_solution(x, 12000)                       # → overflow → single-block fallback
+    ref = np.zeros(len(x))
+    ref[np.argsort(-x, kind="stable")[:12000]] = 1.0
+    np.testing.assert_array_equal(mask, ref)
+    x = np.concatenate([np.full(50, 2.5), rs.randn(5000), np.full(50, 2.5)])   # small tie group
+    mask = mac.round_solution(x, 70)
+    ref = np.zeros(len(x))
+    ref[np.argsort(-x, kind="stable")[:70]] = 1.0
+    np.testing.assert_array_equal(mask, ref)
     x = np.array([1.0, 3.0, 3.0, 3.0, 0.0, 3.0, -1.0])      # ties → lowest index kept
     np.testing.assert_array_equal(mac.round_solution(x, 3), [0, 1, 1, 1, 0, 0, 0])
     np.testing.assert_array_equal(mac.round_solution(x, 0), np.zeros(7))
