@@ -375,6 +375,40 @@ def gen_lcsm():
     print("lcsm_ref.json: events", len(events), "candidates", len(cand), "selected", len(sel))
 
 
+# ----------------------------------------------------------------------------------------------
+# Broker (cslam/broker.py): vertex covers of selections, bipartite (Hopcroft-Karp + Koenig via
+# networkx) and multi-robot (networkx local-ratio 2-approximation), and the random dialog
+# ----------------------------------------------------------------------------------------------
+def gen_broker():
+    from cslam.broker import Broker
+    cases = {}
+    specs = [("bip_2robots", 2, 40, 60, 25), ("bip_dense", 2, 12, 80, 40),
+             ("multi_3robots", 3, 30, 90, 30), ("multi_5robots", 5, 20, 120, 45),
+             ("subset_in_range", 4, 25, 100, 35)]
+    for name, nb_robots, nb_poses, nb_cand, nb_sel in specs:
+        rs = np.random.RandomState(sum(map(ord, name)))
+        _, cand = build_multi_robot_graph(rs, nb_poses, nb_cand, nb_robots)
+        sel = [cand[i] for i in rs.permutation(len(cand))[:nb_sel]]
+        in_range = list(range(nb_robots)) if name != "subset_in_range" else [0, 2, 3]
+        b = Broker(sel, in_range)
+        covers = b.brokerage(True)
+        np.random.seed(99)
+        dialog = Broker(sel, in_range).brokerage(False)
+        cases[name] = dict(selection=_edge_list(sel), in_range=in_range,
+                           is_bipartite=bool(getattr(b, "is_bipartite", False)),
+                           covers=[sorted([list(v) for v in c]) for c in covers],
+                           dialog=[sorted([list(v) for v in c]) for c in dialog])
+    # single robot in range → no brokerage
+    rs = np.random.RandomState(5)
+    _, cand = build_multi_robot_graph(rs, 10, 20, 2)
+    cases["single_robot"] = dict(selection=_edge_list(cand[:5]), in_range=[0],
+                                 covers=Broker(cand[:5], [0]).brokerage(True), dialog=[],
+                                 is_bipartite=False)
+    with open(os.path.join(HERE, "broker_ref.json"), "w") as f:
+        json.dump(cases, f)
+    print("broker_ref.json:", {k: [len(c) for c in v["covers"]] for k, v in cases.items()})
+
+
 if __name__ == "__main__":
     random.seed(0)
     np.random.seed(0)
@@ -382,3 +416,4 @@ if __name__ == "__main__":
     gen_mac()
     gen_acm()
     gen_lcsm()
+    gen_broker()
