@@ -1,0 +1,326 @@
+"""ROS 2 surface of the loop-closure hot path — mirror of
+cslam/global_descriptor_loop_closure_detection.py:27-467 (SURVEY.md §8b ring 1, §8f N1).
+
+Same topics, message types, QoS depth, timers, buffers and log keys as the reference; the
+matching and selection underneath are the HIP implementations of this package.  Differences:
+  * descriptors of one received `GlobalDescriptors` message are matched in ONE device scan
+    (`add_other_robot_global_descriptors`) instead of one scan per descriptor
+    (gdlcd.py:396-404) — same matches, same order of buffer insertion;
+  * only the "descriptor arrives on cslam/processed_global_descriptor" technique is on the path
+    (NetVLAD / ScanContext front ends are out of scope);
+  * the two buffer-pruning loops of the reference delete from a SortedDict while iterating its
+    live key view (gdlcd.py:176-178,188-190); here the keys are snapshotted first — same
+    result without relying on that container's tolerance;
+  * `lcm` may be injected (tests drive the surface on CPU with a stub matcher).
+Works with real rclpy (`node` is the rclpy Node) or with a test double exposing
+create_publisher / create_subscription / create_timer / get_parameter / get_logger.
+"""
+import time
+
+import numpy as np
+from sortedcontainers import SortedDict
+
+from .algebraic_connectivity_maximization import EdgeInterRobot
+from .broker import Broker
+from .neighbors_manager import NeighborManager
+from .ros_compat import (Clock, GlobalDescriptor, GlobalDescriptors, InterRobotLoopClosure,
+                         InterRobotMatch, InterRobotMatches, KeyValue, LocalDescriptorsRequest,
+                         LocalKeyframeMatch)
+from .utils.misc import dict_to_list_chunks
+
+
+class GlobalDescriptorLoopClosureDetection(object):
+    """ Global descriptor matching """
+
+    def __init__(self, params, node, lcm=None):
+        """
+        Args:
+            params (dict): flat ROS parameter dict (loop_closure_detection_node.py:45-89)
+            node: ROS 2 node handle (or test double)
+            lcm: optional LoopClosureSparseMatching-compatible object (default: the HIP one)
+        """
+        self.params = params
+        self.node = node
+        if lcm is None:
+            from .loop_closure_sparse_matching import LoopClosureSparseMatching
+            lcm = LoopClosureSparseMatching(params, node)
+        self.lcm = lcm
+
+        technique = self.params['frontend.global_descriptor_technique'].lower()
+        if technique in ('netvlad', 'scancontext'):
+            raise NotImplementedError(
+                f"global_descriptor_technique '{technique}' computes descriptors inside the node; "
+                "only externally computed descriptors (cosplace & co.) are on the hot path")
+        self.keyframe_type = "rgb"
+
+        p = self.params
+        p['frontend.global_descriptors_topic'] = '/cslam/' + self.node.get_parameter(
+            'frontend.global_descriptors_topic').value
+        self.global_descriptor_publisher = self.node.create_publisher(
+            GlobalDescriptors, p['frontend.global_descriptors_topic'], 100)
+        self.global_descriptor_subscriber = self.node.create_subscription(
+            GlobalDescriptors, p['frontend.global_descriptors_topic'],
+            self.global_descriptor_callback, 100)
+
+        p['frontend.inter_robot_matches_topic'] = '/cslam/' + self.node.get_parameter(
+            'frontend.inter_robot_matches_topic').value
+        self.inter_robot_matches_publisher = self.node.create_publisher(
+            InterRobotMatches, p['frontend.inter_robot_matches_topic'], 100)
+        self.inter_robot_matches_subscriber = self.node.create_subscription(
+            InterRobotMatches, p['frontend.inter_robot_matches_topic'],
+            self.inter_robot_matches_callback, 100)
+
+        self.receive_keyframe_subscriber = self.node.create_subscription(
+            GlobalDescriptor, 'cslam/processed_global_descriptor', self.receive_descriptor, 100)
+        self.local_match_publisher = self.node.create_publisher(
+            LocalKeyframeMatch, 'cslam/local_keyframe_match', 100)
+        self.receive_inter_robot_loop_closure_subscriber = self.node.create_subscription(
+            InterRobotLoopClosure, '/cslam/inter_robot_loop_closure',
+            self.receive_inter_robot_loop_closure, 100)
+        self.local_descriptors_request_publishers = {
+            i: self.node.create_publisher(LocalDescriptorsRequest,
+                                          '/r' + str(i) + '/cslam/local_descriptors_request', 100)
+            for i in range(p['max_nb_robots'])
+        }
+
+        self.neighbor_manager = NeighborManager(self.node, self.params)
+
+        # system clock on purpose (gdlcd.py:110-123: the node lives inside a TimerAction)
+        self.global_descriptors_buffer = SortedDict()
+        self.global_descriptors_timer = self.node.create_timer(
+            p['frontend.detection_publication_period_sec'],
+            self.global_descriptors_timer_callback, clock=Clock())
+        self.inter_robot_matches_buffer = SortedDict()
+        self.nb_inter_robot_matches = 0
+        self.inter_robot_matches_timer = self.node.create_timer(
+            p['frontend.detection_publication_period_sec'],
+            self.inter_robot_matches_timer_callback, clock=Clock())
+
+        if p["evaluation.enable_logs"]:
+            self.log_publisher = self.node.create_publisher(KeyValue, 'cslam/log_info', 100)
+            self.log_matches_publisher = self.node.create_publisher(
+                InterRobotMatches, 'cslam/log_matches', 100)
+            self.log_total_successful_matches = 0
+            self.log_total_failed_matches = 0
+            self.log_total_vertices_transmitted = 0
+            self.log_total_matches_selected = 0
+            self.log_detection_cumulative_communication = 0
+            self.log_total_sparsification_computation_time = 0.0
+        self.gpu_start_time = time.time()
+
+    # ---- local keyframes (gdlcd.py:145-168, 285-303, 385-386) ----------------------------
+    def _buffer_match(self, match):
+        self.inter_robot_matches_buffer[self.nb_inter_robot_matches] = match
+        self.nb_inter_robot_matches += 1
+
+    def add_global_descriptor_to_map(self, embedding, kf_id):
+        """New local keyframe: match against the other robots' pools, intra-robot detection,
+        queue the descriptor and the matches for publication."""
+        matches = self.lcm.add_local_global_descriptor(embedding, kf_id)
+        self.detect_intra(embedding, kf_id)
+        msg = GlobalDescriptor()
+        msg.keyframe_id = kf_id
+        msg.robot_id = self.params['robot_id']
+        msg.descriptor = embedding.tolist()
+        self.global_descriptors_buffer[kf_id] = msg
+        for match in matches:
+            self._buffer_match(match)
+
+    def receive_descriptor(self, msg):
+        self.add_global_descriptor_to_map(np.asarray(msg.descriptor), msg.keyframe_id)
+
+    def detect_intra(self, embedding, kf_id):
+        """Intra-robot loop closure → LocalKeyframeMatch (gdlcd.py:285-303)."""
+        if not self.params['frontend.enable_intra_robot_loop_closures']:
+            return
+        kf_match, similarities = self.lcm.match_local_loop_closures(embedding, kf_id)
+        if kf_match is not None:
+            self.node.get_logger().debug(f"KF similarity ({kf_id},{kf_match}): {similarities}")
+            msg = LocalKeyframeMatch()
+            msg.keyframe0_id = kf_id
+            msg.keyframe1_id = kf_match
+            self.local_match_publisher.publish(msg)
+
+    # ---- periodic publication (gdlcd.py:170-283) -------------------------------------------
+    @staticmethod
+    def _prune(buffer, first_needed):
+        if first_needed >= buffer.peekitem(0)[0]:
+            for k in [k for k in buffer.keys() if k < first_needed]:
+                del buffer[k]
+
+    def delete_useless_descriptors(self):
+        """Drop descriptors every other robot has been sent (gdlcd.py:170-178)."""
+        self._prune(self.global_descriptors_buffer, self.neighbor_manager.useless_descriptors(
+            self.global_descriptors_buffer.peekitem(-1)[0]))
+
+    def delete_useless_inter_robot_matches(self):
+        self._prune(self.inter_robot_matches_buffer, self.neighbor_manager.useless_matches(
+            self.inter_robot_matches_buffer.peekitem(-1)[0]))
+
+    def _log(self, key, value):
+        self.log_publisher.publish(KeyValue(key=key, value=str(value)))
+
+    def global_descriptors_timer_callback(self):
+        """Publish the descriptors the neighbours in range do not have yet, in chunks of
+        `frontend.detection_publication_max_elems_per_msg` (gdlcd.py:192-221)."""
+        buf = self.global_descriptors_buffer
+        if len(buf) == 0:
+            return
+        from_kf_id = self.neighbor_manager.select_from_which_kf_to_send(buf.peekitem(-1)[0])
+        chunks = dict_to_list_chunks(
+            buf, from_kf_id - buf.peekitem(0)[0],
+            self.params['frontend.detection_publication_max_elems_per_msg'])
+        for m in chunks:
+            out = GlobalDescriptors()
+            out.descriptors = m
+            self.global_descriptor_publisher.publish(out)
+            if self.params["evaluation.enable_logs"]:
+                self.log_detection_cumulative_communication += len(m) * len(m[0].descriptor) * 4
+        self.delete_useless_descriptors()
+        if self.params["evaluation.enable_logs"]:
+            self._log("detection_cumulative_communication",
+                      self.log_detection_cumulative_communication)
+
+    def edge_to_match(self, edge):
+        """EdgeInterRobot → InterRobotMatch message."""
+        msg = InterRobotMatch()
+        msg.robot0_id = edge.robot0_id
+        msg.robot0_keyframe_id = edge.robot0_keyframe_id
+        msg.robot1_id = edge.robot1_id
+        msg.robot1_keyframe_id = edge.robot1_keyframe_id
+        msg.weight = float(edge.weight)
+        return msg
+
+    def inter_robot_matches_timer_callback(self):
+        """Publish the matches the neighbours in range do not have yet (gdlcd.py:237-283)."""
+        buf = self.inter_robot_matches_buffer
+        if len(buf) == 0:
+            return
+        from_match_idx = self.neighbor_manager.select_from_which_match_to_send(
+            buf.peekitem(-1)[0])
+        chunks = dict_to_list_chunks(
+            buf, from_match_idx - buf.peekitem(0)[0],
+            self.params['frontend.detection_publication_max_elems_per_msg'])
+        # with exactly two robots in range, a match between those two was found by both:
+        # the reference filters them out while iterating the lists it mutates
+        # (gdlcd.py:253-260), which skips the element after every removal; reproduced as is.
+        _, in_range = self.neighbor_manager.check_neighbors_in_range()
+        if len(in_range) == 2:
+            self.node.get_logger().debug("Transmitting matches {}".format(in_range))
+            for c in chunks:
+                for match in c:
+                    if match.robot0_id in in_range and match.robot1_id in in_range:
+                        c.remove(match)
+                if len(c) <= 0:
+                    chunks.remove(c)
+        for c in chunks:
+            out = InterRobotMatches()
+            out.robot_id = self.params['robot_id']
+            out.matches = [self.edge_to_match(m) for m in c]
+            self.inter_robot_matches_publisher.publish(out)
+            if self.params["evaluation.enable_logs"]:
+                self.log_detection_cumulative_communication += len(out.matches) * 20
+        self.delete_useless_inter_robot_matches()
+        if self.params["evaluation.enable_logs"]:
+            self._log("detection_cumulative_communication",
+                      self.log_detection_cumulative_communication)
+
+    # ---- inter-robot detection (gdlcd.py:305-383) ------------------------------------------
+    def detect_inter(self):
+        """Broker only: select candidates within the budget, decide which endpoints ship their
+        local descriptors, publish the requests."""
+        neighbors_is_in_range, in_range = self.neighbor_manager.check_neighbors_in_range()
+        if not (len(in_range) > 0 and self.neighbor_manager.local_robot_is_broker()):
+            return
+        logs = self.params["evaluation.enable_logs"]
+        if logs:
+            start_time = time.time()
+        selection = self.lcm.select_candidates(
+            int(self.params["frontend.inter_robot_loop_closure_budget"]), neighbors_is_in_range)
+        vertices_info = self.edge_list_to_vertices(selection)
+        broker = Broker(selection, in_range)
+        for vertex_set in broker.brokerage(self.params["frontend.use_vertex_cover_selection"]):
+            for v in vertex_set:
+                msg = LocalDescriptorsRequest()
+                msg.keyframe_id = v[1]
+                msg.matches_robot_id = vertices_info[v][0]
+                msg.matches_keyframe_id = vertices_info[v][1]
+                self.node.get_logger().info(
+                    f"Requesting local descriptors for {msg.matches_robot_id}:"
+                    f"{msg.matches_keyframe_id}")
+                self.local_descriptors_request_publishers[v[0]].publish(msg)
+            if logs:
+                self.log_total_vertices_transmitted += len(vertex_set)
+        if logs:
+            self.log_total_sparsification_computation_time += time.time() - start_time
+            self.log_total_matches_selected += len(selection)
+            self._log("sparsification_cumulative_computation_time",
+                      self.log_total_sparsification_computation_time)
+            self._log("nb_vertices_transmitted", self.log_total_vertices_transmitted)
+            self._log("nb_matches_selected", self.log_total_matches_selected)
+            if self.params["evaluation.enable_sparsification_comparison"]:
+                out = InterRobotMatches()
+                out.robot_id = self.params["robot_id"]
+                for e in self.lcm.candidate_selector.log_mac_edges:
+                    out.matches.append(self.edge_to_match(e))
+                self.log_matches_publisher.publish(out)
+
+    def edge_list_to_vertices(self, selection):
+        """{(robot, kf): [[matched robot ids], [matched kf ids]]} (gdlcd.py:362-383)."""
+        vertices = {}
+        for s in selection:
+            a = (s.robot0_id, s.robot0_keyframe_id)
+            b = (s.robot1_id, s.robot1_keyframe_id)
+            for me, other in ((a, b), (b, a)):
+                slot = vertices.setdefault(me, [[], []])
+                slot[0].append(other[0])
+                slot[1].append(other[1])
+        return vertices
+
+    # ---- messages from other robots (gdlcd.py:388-467) --------------------------------------
+    def global_descriptor_callback(self, msg):
+        """Descriptors received from another robot: one device scan for the whole message."""
+        if msg.descriptors[0].robot_id == self.params['robot_id']:
+            return
+        unknown = self.neighbor_manager.get_unknown_range(msg.descriptors)
+        fresh = [msg.descriptors[i] for i in unknown]
+        if hasattr(self.lcm, "add_other_robot_global_descriptors"):
+            matches = self.lcm.add_other_robot_global_descriptors(fresh)
+        else:
+            matches = [self.lcm.add_other_robot_global_descriptor(d) for d in fresh]
+        for match in matches:
+            if match is not None:
+                self._buffer_match(match)
+
+    def inter_robot_matches_callback(self, msg):
+        """Matches found by another robot feed the local candidate graph."""
+        if msg.robot_id == self.params['robot_id']:
+            return
+        for m in msg.matches:
+            self.node.get_logger().info(f"Received matching KF from: ({msg.robot_id})")
+            self.lcm.candidate_selector.add_match(
+                EdgeInterRobot(m.robot0_id, m.robot0_keyframe_id, m.robot1_id,
+                               m.robot1_keyframe_id, m.weight))
+
+    def inter_robot_loop_closure_msg_to_edge(self, msg):
+        return EdgeInterRobot(msg.robot0_id, msg.robot0_keyframe_id, msg.robot1_id,
+                              msg.robot1_keyframe_id, self.lcm.candidate_selector.fixed_weight)
+
+    def receive_inter_robot_loop_closure(self, msg):
+        """Geometric verification result: success → candidate becomes a fixed edge, failure →
+        candidate removed and blacklisted (gdlcd.py:432-467)."""
+        edge = self.inter_robot_loop_closure_msg_to_edge(msg)
+        what = 'New' if msg.success else 'Failed'
+        self.node.get_logger().info(
+            f'{what} inter-robot loop closure measurement: ({msg.robot0_id},'
+            f'{msg.robot0_keyframe_id}) -> ({msg.robot1_id},{msg.robot1_keyframe_id})')
+        if msg.success:
+            self.lcm.candidate_selector.candidate_edges_to_fixed([edge])
+            if self.params["evaluation.enable_logs"]:
+                self.log_total_successful_matches += 1
+                self._log("nb_matches", self.log_total_successful_matches)
+        else:
+            self.lcm.candidate_selector.remove_candidate_edges([edge], failed=True)
+            if self.params["evaluation.enable_logs"]:
+                self.log_total_failed_matches += 1
+                self._log("nb_failed_matches", self.log_total_failed_matches)
