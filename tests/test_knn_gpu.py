@@ -212,7 +212,7 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
 
 def test_full_size_properties(gpu):
     """BASELINE cfg2 size (100k x 4096) through size-independent properties: every sampled pool
-    row retrieves itself first with similarity 1 (to 2e-7), results are sorted, a duplicated row
+    row retrieves itself first with similarity 1 (to 1e-6), results are sorted, a duplicated row
     ties and resolves to the lower index, and search is idempotent."""
     torch = pytest.importorskip("torch")
     import ctypes
@@ -248,7 +248,7 @@ def test_full_size_properties(gpu):
     expect_first = probe.cpu().numpy().copy()
     expect_first[4] = 123                                     # duplicate → lower row wins
     np.testing.assert_array_equal(i1[:, 0], expect_first)
-    assert np.all(np.abs(s1[:, 0] - 1.0) < 2e-7)
+    assert np.all(np.abs(s1[:, 0] - 1.0) < 1e-6)              # fp32, 4096 terms
     assert i1[1, 1] == 77_777 and s1[1, 0] == s1[1, 1]        # the tie partner comes second
     assert len(set(map(int, i1[0]))) == 10                    # no duplicates in a result list
     # the oracle on the rows that won (cheap: 10 rows) reproduces the similarities bit for bit
