@@ -111,15 +111,16 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
                                                        int64_t q_stride, int dim, int m,
                                                        int mq_pad, int dp,
                                                        float* __restrict__ stage,
-                                                       float* __restrict__ rnq, int vec_ok) {
+                                                       float* __restrict__ rnq, int vec_ok,
+                                                       int64_t copy_stride) {
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     if (w >= mq_pad) return;
-    float* d = stage + (int64_t)w * dp;
+    float* d = stage + (int64_t)blockIdx.y * copy_stride + (int64_t)w * dp;
     if (w >= m) {
         for (int k = tid * 4; k < dp; k += 1024)
             *reinterpret_cast<f32x4*>(d + k) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tid == 0) rnq[w] = 0.0f;
+        if (tid == 0 && blockIdx.y == 0) rnq[w] = 0.0f;
         return;
     }
     const float* s = q + (int64_t)w * q_stride;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
                       ld_or_zero(s, k + 3, dim)};
         *reinterpret_cast<f32x4*>(d + k) = v;
     }
-    if (tid < 64) {
+    if (tid < 64 && blockIdx.y == 0) {
         const int lane = tid;
         float ss = 0.0f;
         for (int base0 = 4 * lane; base0 < dp; base0 += 256 * 8) {
@@ -188,9 +189,13 @@ template <int T, int S, int U, int G = 1>
 __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64_t xs, int64_t n,
                                               int dp, const float* __restrict__ Q, int m_valid,
                                               float* __restrict__ dots, int64_t dots_stride,
-                                              int64_t n_waves) {
+                                              int64_t n_waves, int q_copies,
+                                              int64_t q_copy_stride) {
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_waves) return;
+    // replicas of the staged query block at different addresses spread the lockstep query
+    // reads of all waves over more L2 channels
+    Q += (w % q_copies) * q_copy_stride;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15;
     const int g = lane >> 4;
@@ -439,6 +444,195 @@ __global__ __launch_bounds__(NW * 64) void k_scan_lds(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_scan_pc<S,NWV>: producer/consumer scan (<= 16 queries).
+//   Measured: whatever a CU pulls through its L1-miss path — HBM rows or L2-resident queries —
+//   shares one budget of ~10.6 B/clk (≈6.5 TB/s chip-wide): with the queries loaded from L2 the
+//   X stream is capped at 6.5/(1+1/S) TB/s (S = 8 → 5.3 measured).  Here the queries never use
+//   that path: wave 0 of each block (one block per CU) streams the staged query block into a
+//   deep LDS ring, stage by stage (256 floats x 16 columns), and the other NWV-1 waves read
+//   their B fragments from LDS.  No barriers: the producer publishes `ready` (stages filled),
+//   every consumer publishes its own progress; the producer refills a slot once all consumers
+//   are past it.  Consumers drift up to kPcRing-1 stages apart, so one wave's slow HBM burst
+//   does not stall the others (the per-stage barrier of k_scan_lds did exactly that).
+//   X path, MFMA order and chunk folds are those of k_scan → identical bits.
+//   Every spin is bounded: on timeout the wave sets *fault and leaves (no hung GPU).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPcStageKb = 16;                       // k-blocks per query stage (256 floats)
+constexpr int kPcPitch = kPcStageKb * 16 + 4;        // floats per query column per stage
+constexpr int kPcRing = 8;                           // stages in the LDS ring
+constexpr int kPcSpinMax = 1 << 22;
+
+template <int S, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ X, int64_t xs,
+                                                      int64_t n, int dp,
+                                                      const float* __restrict__ Q, int m_valid,
+                                                      float* __restrict__ dots,
+                                                      int64_t dots_stride, int64_t n_cons,
+                                                      int ngroups, int* __restrict__ fault) {
+    extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+    float* qs = pc_lds;                                           // [kPcRing][16 * kPcPitch]
+    int* ready = reinterpret_cast<int*>(pc_lds + kPcRing * 16 * kPcPitch);   // stages published
+    int* progress = ready + 1;                                    // [NWV] stages consumed
+    constexpr int NC = NWV - 1;
+    constexpr int UB = 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nkb = dp >> 4;
+    const int nstage = (nkb + kPcStageKb - 1) / kPcStageKb;
+    const int total = ngroups * nstage;
+
+    if (tid == 0) *ready = 0;
+    if (tid < NWV) progress[tid] = 0;
+    __syncthreads();
+
+    if (wave == 0) {
+        // ---------------- producer: query stages → LDS ring ----------------
+        for (int j = 0; j < total; ++j) {
+            const int st = j % nstage;
+            f32x4 qreg[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = lane + i * 64;                 // float4 index in the stage tile
+                const int c = f / (kPcStageKb * 4);
+                const int jj = f % (kPcStageKb * 4);
+                const int k = st * (kPcStageKb * 16) + 4 * jj;
+                qreg[i] = (k < dp) ? *reinterpret_cast<const f32x4*>(Q + (int64_t)c * dp + k)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (j >= kPcRing) {  // slot still in use? wait for the slowest consumer
+                int spins = 0;
+                while (true) {
+                    int mn = 1 << 30;
+                    for (int cw = 1; cw < NWV; ++cw) {
+                        int pv = __hip_atomic_load(&progress[cw], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        mn = pv < mn ? pv : mn;
+                    }
+                    if (mn >= j - kPcRing + 1) break;
+                    if (++spins > kPcSpinMax) {
+                        if (lane == 0) *fault = 1;
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            float* slot = qs + (j % kPcRing) * (16 * kPcPitch);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = lane + i * 64;
+                const int c = f / (kPcStageKb * 4);
+                const int jj = f % (kPcStageKb * 4);
+                *reinterpret_cast<f32x4*>(slot + c * kPcPitch + 4 * jj) = qreg[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+
+    // ---------------- consumers ----------------
+    // Two register buffers (one per half stage = 8 k-blocks x S strips), each refilled for the
+    // NEXT stage right after it is consumed: a wave always has a full stage of X in flight,
+    // across stage and group boundaries, and X loads never wait for the query ring.
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int64_t w = (int64_t)blockIdx.x * NC + (wave - 1);
+    const int64_t lo = w < n_cons ? (w * n) / n_cons : 0;
+    const int64_t hi = w < n_cons ? ((w + 1) * n) / n_cons : 0;
+
+    f32x4 bufA[UB][S], bufB[UB][S];
+    auto issue = [&](f32x4 (&buf)[UB][S], int grp, int st, int half) {
+        // branch-free (nkb % kPcStageKb == 0 is a launch precondition): rows past the range
+        // and the prefetch past the last group are clamped — duplicates hit L1, never stored
+        const int kb0 = st * kPcStageKb + half * UB;
+        const int gq = grp < ngroups ? grp : ngroups - 1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            int64_t row = lo + (int64_t)gq * (16 * S) + 16 * s + r;
+            if (row >= hi) row = hi - 1;
+            if (row < 0) row = 0;
+            const f32x4* xp = reinterpret_cast<const f32x4*>(X + row * xs + 4 * g) + kb0 * 4;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) buf[u][s] = xp[u * 4];
+        }
+    };
+    f32x4 tot[S], acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto compute = [&](const f32x4 (&buf)[UB][S], const float* qrow, int st, int half) {
+        (void)st;
+        f32x4 b[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            b[u] = *reinterpret_cast<const f32x4*>(qrow + (half * UB + u) * 16);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx)
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[u][s][jx], b[u][jx], acc[s], 0,
+                                                                  0, 0);
+    };
+    issue(bufA, 0, 0, 0);
+    issue(bufB, 0, 0, 1);
+    int j = 0;
+    for (int grp = 0; grp < ngroups; ++grp) {
+        for (int st = 0; st < nstage; ++st, ++j) {
+            const int ngrp = st + 1 < nstage ? grp : grp + 1;
+            const int nst = st + 1 < nstage ? st + 1 : 0;
+            {
+                int spins = 0;
+                while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) {
+                    if (++spins > kPcSpinMax) {
+                        if (lane == 0) *fault = 2;
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            const float* qrow = qs + (j % kPcRing) * (16 * kPcPitch) + r * kPcPitch + 4 * g;
+            compute(bufA, qrow, st, 0);
+            issue(bufA, ngrp, nst, 0);
+            compute(bufB, qrow, st, 1);
+            issue(bufB, ngrp, nst, 1);
+            // chunk fold every kChunkKb k-blocks and at the end of the row
+            if (((st + 1) * kPcStageKb) % kChunkKb == 0 || st + 1 == nstage) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    tot[s] = tot[s] + acc[s];
+                    acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            // this wave is done with stage j (its LDS reads have returned: the MFMAs used them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_store(&progress[wave], j + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (r < m_valid) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t r0 = lo + (int64_t)grp * (16 * S) + 16 * s + 4 * g;
+                float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < hi) out[e] = tot[s][e];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // cosine scaling of raw dots in place: sims[q][i] = (dot * rnx[i]) * rnq[q]
 __global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t stride, int64_t n,
                                                const float* __restrict__ rnx,
@@ -590,10 +784,12 @@ struct cslam_pool {
     int64_t n = 0, cap = 0;
     int64_t xs = 0;             // row stride in floats (dp + anti-camping pad)
     int64_t v0 = 0, vn = 0;     // row window [v0, v0+vn) of the search in flight
+    int q_copies = 1;           // replicas of the staged query block (T = 1 path)
+    int64_t q_copy_stride = 0;  // floats between replicas
     float* rows = nullptr;      // [cap][dp]
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
-    DevBuf qstage, rnq, sims, cand_a, cand_b, comp;
+    DevBuf qstage, rnq, sims, cand_a, cand_b, comp, fault;
     DevBuf h_q, h_idx, h_sim;  // device staging of the host-pointer API
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
@@ -648,7 +844,7 @@ void launch_scan_t(cslam_pool* p, const float* Q, int m_valid, float* dots, int6
     constexpr int G = (T == 1) ? U : 1;
     hipLaunchKernelGGL((k_scan<T, S, U, G>), dim3(blocks), dim3(256), 0, st,
                        p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, m_valid, dots,
-                       dots_stride, n_waves);
+                       dots_stride, n_waves, p->q_copies, p->q_copy_stride);
 }
 
 template <int T, int S, int UMAX>
@@ -671,7 +867,7 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     static const int wpc_env = getenv("CSLAM_SCAN_WPC") ? atoi(getenv("CSLAM_SCAN_WPC")) : 0;
     static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
     const int wpc = wpc_env > 0 ? wpc_env : 4;  // waves per CU (profiles/r01_scan_sweep*.txt)
-    const int S = s_env == 4 ? 4 : 8;  // strips sharing one query fragment (T = 1 path)
+    const int S = (s_env == 1 || s_env == 2 || s_env == 4 || s_env == 16) ? s_env : 8;  // strips per query fragment (T = 1)
     const int s_eff = (m <= 16) ? S : 4;
     int64_t groups = (p->vn + 16 * s_eff - 1) / (16 * s_eff);
     int64_t resident = (int64_t)p->cus * wpc;
@@ -685,7 +881,44 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         // LDS-staged variant (4.5-4.9 TB/s measured: the per-stage barrier couples 8 waves'
         // HBM latencies; kept for A/B runs, profiles/r01_scan_lds_vs_ring.txt)
         const bool use_lds = kern_env && strcmp(kern_env, "lds") == 0;
-        if (use_lds) {
+        const bool use_pc = kern_env && strcmp(kern_env, "pc") == 0;
+        if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
+            static const int ps_env = getenv("CSLAM_SCAN_PS") ? atoi(getenv("CSLAM_SCAN_PS")) : 0;
+            static const int pw_env = getenv("CSLAM_SCAN_PW") ? atoi(getenv("CSLAM_SCAN_PW")) : 0;
+            const int PS = ps_env == 1 ? 1 : 2;
+            const int NWV = pw_env == 8 ? 8 : (pw_env == 12 ? 12 : 16);
+            const int NC = NWV - 1;
+            int64_t strips = (p->vn + 15) / 16;
+            int64_t blocks = (strips + NC - 1) / NC;
+            if (blocks > (int64_t)p->cus) blocks = p->cus;
+            if (blocks < 1) blocks = 1;
+            const int64_t nc = blocks * NC < p->vn ? blocks * NC : (p->vn > 0 ? p->vn : 1);
+            const int64_t rows_max = (p->vn + nc - 1) / nc;
+            const int ngroups = (int)((rows_max + 16 * PS - 1) / (16 * PS));
+            const size_t lds = (size_t)kPcRing * 16 * kPcPitch * sizeof(float) + (1 + 16) * sizeof(int);
+            CSLAM_TRY(p->fault.reserve(sizeof(int)));
+            CSLAM_HIP_TRY(hipMemsetAsync(p->fault.p, 0, sizeof(int), st));
+#define CSLAM_PC_LAUNCH(SS, WW)                                                                   \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_pc<SS, WW>,                     \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds));                                         \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_scan_pc<SS, WW>), dim3((unsigned)blocks), dim3(WW * 64), lds, st,   \
+                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,         \
+                           dots_stride, nc, ngroups, p->fault.as<int>());                         \
+    } while (0)
+            if (PS == 1 && NWV == 16) CSLAM_PC_LAUNCH(1, 16);
+            else if (PS == 1 && NWV == 12) CSLAM_PC_LAUNCH(1, 12);
+            else if (PS == 1) CSLAM_PC_LAUNCH(1, 8);
+            else if (NWV == 16) CSLAM_PC_LAUNCH(2, 16);
+            else if (NWV == 12) CSLAM_PC_LAUNCH(2, 12);
+            else CSLAM_PC_LAUNCH(2, 8);
+#undef CSLAM_PC_LAUNCH
+        } else if (use_lds) {
             static const int ls_env = getenv("CSLAM_SCAN_LS") ? atoi(getenv("CSLAM_SCAN_LS")) : 0;
             static const int bpc_env = getenv("CSLAM_SCAN_BPC") ? atoi(getenv("CSLAM_SCAN_BPC")) : 0;
             const int LS = ls_env == 2 ? 2 : 1;
@@ -706,10 +939,24 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
                 hipLaunchKernelGGL((k_scan_lds<1, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
                                    p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
                                    dots_stride, nw, ngroups);
-        } else if (S == 4)
-            launch_scan_u<1, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
-        else
-            launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        } else {
+            static const int u_env = getenv("CSLAM_SCAN_U") ? atoi(getenv("CSLAM_SCAN_U")) : 0;
+            const int U = u_env == 8 ? 8 : 4;
+            if (S == 1 && U == 8)
+                launch_scan_u<1, 1, 8>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else if (S == 2 && U == 8)
+                launch_scan_u<1, 2, 8>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else if (S == 2)
+                launch_scan_u<1, 2, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else if (S == 4 && U == 8)
+                launch_scan_u<1, 4, 8>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else if (S == 4)
+                launch_scan_u<1, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else if (S == 16)
+                launch_scan_u<1, 16, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+            else
+                launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        }
     } else if (m <= 32) {
         launch_scan_u<2, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
     } else {
@@ -727,7 +974,12 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
 // p->rnq[0..m) with 1/max(||q||,1e-8)
 int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* dots,
                  int64_t dots_stride, hipStream_t st) {
-    CSLAM_TRY(p->qstage.reserve((size_t)kMaxQueriesPerPass * p->dp * sizeof(float)));
+    static const int qrep_env = getenv("CSLAM_SCAN_QREP") ? atoi(getenv("CSLAM_SCAN_QREP")) : 0;
+    const int qrep_max = qrep_env > 0 ? qrep_env : 1;
+    // replica stride: the block plus an odd number of 256-B lines so replicas start on
+    // different channels
+    const int64_t copy_stride = (int64_t)kMaxQueriesPerPass * p->dp + 64 * 7;
+    CSLAM_TRY(p->qstage.reserve((size_t)qrep_max * copy_stride * sizeof(float)));
     CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
     for (int q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
         int mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
@@ -736,9 +988,11 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         // behind pass i's scan
         const float* qsrc = q_dev + (int64_t)q0 * q_stride;
         const int vec_ok = ((reinterpret_cast<uintptr_t>(qsrc) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad), dim3(256), 0, st, qsrc, q_stride, p->dim,
-                           mb, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>() + q0,
-                           vec_ok);
+        p->q_copies = mb <= 16 ? qrep_max : 1;
+        p->q_copy_stride = copy_stride;
+        hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, p->q_copies), dim3(256), 0, st, qsrc,
+                           q_stride, p->dim, mb, mq_pad, p->dp, p->qstage.as<float>(),
+                           p->rnq.as<float>() + q0, vec_ok, copy_stride);
         CSLAM_HIP_TRY(hipGetLastError());
         CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), mb, dots + (int64_t)q0 * dots_stride,
                               dots_stride, st));
@@ -900,6 +1154,7 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_a.release();
     p->cand_b.release();
     p->comp.release();
+    p->fault.release();
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();

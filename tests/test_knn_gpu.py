@@ -190,24 +190,25 @@ def test_range_search_and_sharded_step_on_gpu(gpu):
 
 
 def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
-    """CSLAM_SCAN_KERNEL=lds (block-synchronous, LDS-staged query tiles) must give the same
-    bits as the default register-ring kernel: both implement the one canonical order."""
+    """CSLAM_SCAN_KERNEL=lds (block-synchronous LDS-staged query tiles) and =pc (producer /
+    consumer LDS ring) must give the same bits as the default register-ring kernel: all three
+    implement the one canonical order."""
     import subprocess, sys, os, json
     code = (
         "import sys, json, numpy as np; sys.path.insert(0, '.');"
         "from cslam_amd.nns_matching import NearestNeighborsMatching;"
-        "rs = np.random.RandomState(8); X = rs.randn(3333, 200).astype(np.float32);"
-        "Q = rs.randn(7, 200).astype(np.float32); m = NearestNeighborsMatching();"
+        "rs = np.random.RandomState(8); X = rs.randn(3333, 512).astype(np.float32);"
+        "Q = rs.randn(7, 512).astype(np.float32); m = NearestNeighborsMatching();"
         "m.add_items(X, list(range(3333))); r, s = m.search_batch(Q, 10);"
         "print(json.dumps([r.tolist(), s.view(np.int32).tolist()]))")
     outs = []
-    for kern in ("ring", "lds"):
+    for kern in ("ring", "lds", "pc"):
         env = dict(os.environ, CSLAM_SCAN_KERNEL=kern)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert out.returncode == 0, out.stderr
         outs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
 
 
 def test_full_size_properties(gpu):

@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void k_glds(const float* X, size_t n_rows, siz
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
+__global__ void k_fill_random(float* X, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * 256) { unsigned long long h = i * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; X[i] = (float)(h & 0xFFFFFF) / 16777216.0f; }
+}
 template <class F> void timeit(const char* name, F&& launch, size_t bytes) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
@@ -108,6 +112,7 @@ template <class F> void timeit(const char* name, F&& launch, size_t bytes) {
 int main() {
     const size_t N = 100000;
     float *X, *out; hipMalloc(&X, N * D * 4); hipMalloc(&out, 4); hipMemset(X, 0, N * D * 4);
+    if (getenv("PROBE_RANDOM")) { hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, X, N * D); hipDeviceSynchronize(); printf("X filled with random floats\n"); }
     size_t bytes = N * D * 4;
 #define RUN16(S, U, WPC) timeit("rows16x64 S=" #S " U=" #U " wpc=" #WPC, [&] { size_t nw = 256 * WPC; hipLaunchKernelGGL((k_rows16<S, U>), dim3(nw / 4), dim3(256), 0, 0, X, N, nw, out); }, bytes)
 #define RUN8(S, U, WPC) timeit("rows8x128 S=" #S " U=" #U " wpc=" #WPC, [&] { size_t nw = 256 * WPC; hipLaunchKernelGGL((k_rows8<S, U>), dim3(nw / 4), dim3(256), 0, 0, X, N, nw, out); }, bytes)
