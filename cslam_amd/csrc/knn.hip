@@ -15,6 +15,7 @@
 //   k_select<...>   exact top-k (k <= 128): per-part k rounds of block arg-max on
 //                   (similarity desc, row asc) composites, wave-shuffle + LDS reduction
 //   k_bitonic_step  any k: full bitonic sort of the composites in HBM (rare path)
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -633,6 +634,138 @@ __global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm32: raw dots for MANY queries (the MFMA-bound regime, >= 96 queries per call).
+//   LDS-tiled fp32 GEMM on v_mfma_f32_32x32x2_f32: block = 4 waves (2 x 2), block tile
+//   128 rows x 128 queries, K step = one 16-float block; every wave owns 64 x 64 outputs as
+//   2 x 2 MFMA tiles.  The canonical chain order of DESIGN.md §3 maps onto the 2-slot MFMA as
+//   (k, k+4) pairs: lane (row, h) holds v0 = X[row][16kb + 4h ..+3] and v1 = X[row][16kb + 8 +
+//   4h ..+3]; the 8 MFMAs of a block consume v0[0], v1[0], v0[1], v1[1], ... — i.e. k = 0,4,8,12,
+//   1,5,9,13, ... exactly the order of the 16x16x4 path, so similarities are bit-identical to the
+//   streaming scan.  Chunk partials are folded every 32 k-blocks like everywhere else.
+//   Operands go HBM/L2 → registers (prefetched one step ahead) → LDS (row pitch 20 floats:
+//   conflict-free ds_read_b128) → MFMA.  Blocks are ordered so that the 128-row X tile is
+//   consumed by ONE XCD for all its query tiles back to back (first read from HBM, the rest
+//   from that XCD's L2).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kGemmPitch = 20;
+
+__global__ __launch_bounds__(256, 2) void k_gemm32(const float* __restrict__ X, int64_t xs,
+                                                   int64_t n, int dp,
+                                                   const float* __restrict__ Q, int m_valid,
+                                                   float* __restrict__ dots, int64_t dots_stride,
+                                                   int n_rowblk, int n_colblk) {
+    __shared__ __attribute__((aligned(16))) float As[2][128 * kGemmPitch];
+    __shared__ __attribute__((aligned(16))) float Bs[2][128 * kGemmPitch];
+    // XCD-aware tile order: block b runs on XCD b % 8 (dispatch is round-robin); give that XCD
+    // row blocks xcd, xcd + 8, ... and walk the query tiles of a row block consecutively
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int t = b >> 3;
+    const int colblk = t % n_colblk;
+    const int rowblk = (t / n_colblk) * 8 + xcd;
+    if (rowblk >= n_rowblk) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nkb = dp >> 4;
+
+    // staging assignment: thread → (tile row tid/2, float4 columns 2*(tid&1), +1)
+    const int srow = tid >> 1;
+    const int sc4 = (tid & 1) * 2;
+    int64_t xrow = (int64_t)rowblk * 128 + srow;
+    if (xrow >= n) xrow = n - 1;  // clamp: results of clamped rows are not stored
+    const f32x4* xg = reinterpret_cast<const f32x4*>(X + xrow * xs) + sc4;
+    const f32x4* qg = reinterpret_cast<const f32x4*>(Q + (int64_t)(colblk * 128 + srow) * dp) + sc4;
+    float* as_w = &As[0][srow * kGemmPitch + sc4 * 4];
+    float* bs_w = &Bs[0][srow * kGemmPitch + sc4 * 4];
+
+    f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                tot[i][j][e] = 0.f;
+            }
+
+    f32x4 pa0 = xg[0], pa1 = xg[1], pb0 = qg[0], pb1 = qg[1];
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        // stage step kb
+        *reinterpret_cast<f32x4*>(as_w + buf * 128 * kGemmPitch) = pa0;
+        *reinterpret_cast<f32x4*>(as_w + buf * 128 * kGemmPitch + 4) = pa1;
+        *reinterpret_cast<f32x4*>(bs_w + buf * 128 * kGemmPitch) = pb0;
+        *reinterpret_cast<f32x4*>(bs_w + buf * 128 * kGemmPitch + 4) = pb1;
+        if (kb + 1 < nkb) {  // prefetch step kb+1 while this one is consumed
+            pa0 = xg[(kb + 1) * 4];
+            pa1 = xg[(kb + 1) * 4 + 1];
+            pb0 = qg[(kb + 1) * 4];
+            pb1 = qg[(kb + 1) * 4 + 1];
+        }
+        __syncthreads();
+        f32x4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* ap = &As[buf][(wr * 64 + i * 32 + r32) * kGemmPitch + 4 * h];
+            a0[i] = *reinterpret_cast<const f32x4*>(ap);
+            a1[i] = *reinterpret_cast<const f32x4*>(ap + 8);
+            const float* bp = &Bs[buf][(wc * 64 + i * 32 + r32) * kGemmPitch + 4 * h];
+            b0[i] = *reinterpret_cast<const f32x4*>(bp);
+            b1[i] = *reinterpret_cast<const f32x4*>(bp + 8);
+        }
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j4], b0[j][j4],
+                                                                     acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j4], b1[j][j4],
+                                                                     acc[i][j], 0, 0, 0);
+        }
+        if ((kb + 1) % kChunkKb == 0 || kb + 1 == nkb) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    tot[i][j] = tot[i][j] + acc[i][j];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                }
+        }
+        // the double buffer makes one barrier per step enough: step kb+1 writes the other
+        // buffer, and nobody can reach step kb+2's writes before passing step kb+1's barrier
+    }
+    // epilogue: lane holds D[row = (e&3) + 8*(e>>2) + 4h][col = r32] of every 32x32 tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = colblk * 128 + wc * 64 + j * 32 + r32;
+            if (q < m_valid) {
+                float* out = dots + (int64_t)q * dots_stride;
+                const int64_t rb = (int64_t)rowblk * 128 + wr * 64 + i * 32 + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = rb + (e & 3) + 8 * (e >> 2);
+                    if (row < n) out[row] = tot[i][j][e];
+                }
+            }
+        }
+}
+
 // cosine scaling of raw dots in place: sims[q][i] = (dot * rnx[i]) * rnq[q]
 __global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t stride, int64_t n,
                                                const float* __restrict__ rnx,
@@ -979,8 +1112,34 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
     // replica stride: the block plus an odd number of 256-B lines so replicas start on
     // different channels
     const int64_t copy_stride = (int64_t)kMaxQueriesPerPass * p->dp + 64 * 7;
-    CSLAM_TRY(p->qstage.reserve((size_t)qrep_max * copy_stride * sizeof(float)));
+    CSLAM_TRY(p->qstage.reserve(std::max((size_t)qrep_max * copy_stride,
+                                         (size_t)(kQueryChunk + 128) * p->dp) * sizeof(float)));
     CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+    static const int gemm_env = getenv("CSLAM_GEMM") ? atoi(getenv("CSLAM_GEMM")) : 1;
+    if (gemm_env && m >= 96 && p->vn > 0) {
+        // MFMA-bound regime: stage the whole chunk once (padded to 128-query tiles), one GEMM
+        const int mq_pad = (m + 127) / 128 * 128;
+        CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+        const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim,
+                           m, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>(), vec_ok,
+                           (int64_t)0);
+        CSLAM_HIP_TRY(hipGetLastError());
+        const int n_rowblk = (int)((p->vn + 127) / 128);
+        const int n_colblk = mq_pad / 128;
+        const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
+        bool prof = p->prof_on && p->prof_n < p->prof_max;
+        if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+        hipLaunchKernelGGL(k_gemm32, dim3((unsigned)nblocks), dim3(256), 0, st,
+                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, p->qstage.as<float>(), m,
+                           dots, dots_stride, n_rowblk, n_colblk);
+        CSLAM_HIP_TRY(hipGetLastError());
+        if (prof) {
+            CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
+            p->prof_n++;
+        }
+        return CSLAM_OK;
+    }
     for (int q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
         int mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
         int mq_pad = mb <= 16 ? 16 : (mb <= 32 ? 32 : 64);
@@ -1183,7 +1342,7 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
         return fail(CSLAM_E_INVALID, "pool_add_dev: bad args");
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
     hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
                        row_stride, p->dim, p->rows + p->n * p->xs, p->xs, p->dp, n_rows);
@@ -1235,7 +1394,7 @@ int cslam_pool_search_dev(cslam_pool_t* p, const float* queries_dev, int64_t que
         ((int64_t)n_queries * k > 0 && (!out_idx_dev || !out_sim_dev)))
         return fail(CSLAM_E_INVALID, "pool_search_dev: bad args");
     CSLAM_HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev,
                            st);
 }
@@ -1248,7 +1407,7 @@ int cslam_pool_search_range_dev(cslam_pool_t* p, const float* queries_dev, int64
         ((int64_t)n_queries * k > 0 && (!out_idx_dev || !out_sim_dev)))
         return fail(CSLAM_E_INVALID, "pool_search_range_dev: bad args");
     CSLAM_HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev, st,
                            row_lo, row_hi);
 }
@@ -1261,7 +1420,7 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
         return fail(CSLAM_E_INVALID, "pool_similarities_dev: bad args");
     if (n_queries == 0 || p->n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = stream ? (hipStream_t)stream : p->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     p->v0 = 0;
     p->vn = p->n;
     for (int q0 = 0; q0 < n_queries; q0 += (int)kQueryChunk) {

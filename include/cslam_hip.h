@@ -15,7 +15,9 @@
  *   - every function returns 0 on success, <0 on error (CSLAM_E_*); the message of the last
  *     error on the calling thread is returned by cslam_last_error().
  *   - `*_dev` arguments are device (HBM) pointers, everything else is host memory owned by
- *     the caller.  `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *     the caller.  `stream` is a hipStream_t passed as void*; NULL is the default (null) stream,
+ *     i.e. what `torch.cuda.current_stream().cuda_stream` is unless the caller changed it.
+ *     Host-pointer entry points run on a private stream and return synchronised.
  *   - one caller thread per handle (the reference node is a single-threaded rclpy executor).
  *   - no torch types, no C++ types.
  */

@@ -40,6 +40,9 @@ def _check(gpu, X, Q, k):
     (3000, 256, 20, 3),       # T=2 scan
     (9000, 48, 300, 64),      # query chunking (> 256 queries), k = 64
     (600, 33, 2, 200),        # bitonic path, ragged dim
+    (2000, 4096, 130, 10),    # LDS-tiled 32x32x2 GEMM path (>= 96 queries), ragged row/query tiles
+    (777, 100, 256, 5),       # GEMM path, ragged dim, full 256-query chunk
+    (129, 16, 97, 129),       # GEMM path, one k-block, k == n (bitonic select)
 ])
 def test_search_matches_oracle(gpu, n, d, m, k):
     rs = np.random.RandomState(n * 31 + d)
