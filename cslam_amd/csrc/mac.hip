@@ -275,25 +275,10 @@ __device__ inline Aff block_scan_aff(Aff v, Aff* smem /* [256] */, int pos) {
 //   backward  z_i = y_i * invd_i - l_i z_{i+1}          (i descending)
 // Both sweeps use the SAME partition (block b owns nodes [1024 b, 1024 b + 1024), thread t four
 // consecutive nodes), so the forward apply can emit the backward block composites from the y
-// values it still holds in registers: 3 launches per solve instead of 4.
+// values it still holds in registers, and the forward composites of the NEXT solve are emitted
+// by the Ritz update that produces its right-hand side (k_update_fwd_agg): 2 launches per solve.
 __device__ inline Aff fwd_elem(int i, const double* __restrict__ r, const double* __restrict__ l) {
     return Aff{i > 0 ? -l[i - 1] : 0.0, r[i]};
-}
-
-// (1) forward block composites
-__global__ __launch_bounds__(kScanThreads) void k_fwd_agg(const double* __restrict__ r,
-                                                          const double* __restrict__ l, int n,
-                                                          Aff* __restrict__ agg_f,
-                                                          const Scalars* sc) {
-    if (sc->done) return;
-    __shared__ Aff smem[kScanThreads];
-    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
-    Aff t{1.0, 0.0};
-#pragma unroll
-    for (int e = 0; e < kScanElems; ++e)
-        if (i0 + e < n) t = compose(t, fwd_elem(i0 + e, r, l));
-    Aff inc = block_scan_aff(t, smem, threadIdx.x);
-    if (threadIdx.x == kScanThreads - 1) agg_f[blockIdx.x] = inc;
 }
 
 // value entering a block: the composites of the blocks before it (in sweep order) applied to 0,
@@ -473,6 +458,55 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) partial[blockIdx.x * 12 + i] = v[i];
+    }
+}
+
+// Aw = L w fused with the 12 Gram dot products (one thread per row: the products of row i only
+// need row i of every vector, so the mat-vec result never has to be re-read) — one launch less
+// per iteration.  partial[] has one slot per block of 256 rows.
+__global__ __launch_bounds__(256) void k_spmv_dots(const int32_t* __restrict__ adj_ptr,
+                                                   const int32_t* __restrict__ adj_nbr,
+                                                   const double* __restrict__ aw,
+                                                   const double* __restrict__ x,
+                                                   const double* __restrict__ w,
+                                                   const double* __restrict__ p,
+                                                   const double* __restrict__ Ax,
+                                                   double* __restrict__ Aw,
+                                                   const double* __restrict__ Ap, int n,
+                                                   const double* __restrict__ psum, int nscan,
+                                                   double* __restrict__ partial,
+                                                   const Scalars* sc) {
+    if (sc->done) return;
+    __shared__ double smem[12 * 4];
+    const double mu = mean_from_psum(psum, nscan, n);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) v[q] = 0.0;
+    if (i < n) {
+        const double wraw = w[i];
+        double acc = 0.0;
+        for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) acc += aw[e] * (wraw - w[adj_nbr[e]]);
+        Aw[i] = acc;
+        const double xi = x[i], wi = wraw - mu, pi = p[i];
+        const double axi = Ax[i], api = Ap[i];
+        v[0] = xi * xi;
+        v[1] = xi * wi;
+        v[2] = xi * pi;
+        v[3] = wi * wi;
+        v[4] = wi * pi;
+        v[5] = pi * pi;
+        v[6] = xi * axi;
+        v[7] = xi * acc;
+        v[8] = xi * api;
+        v[9] = wi * acc;
+        v[10] = wi * api;
+        v[11] = pi * api;
+    }
+    block_sum<12>(v, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) partial[blockIdx.x * 12 + q] = v[q];
     }
 }
 
@@ -712,7 +746,8 @@ __device__ inline bool rr_try(const double (&GB)[3][3], const double (&GA)[3][3]
 __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ partial, int nblk,
                                                   const double* __restrict__ psum, int nscan,
                                                   int use_mu, int n,
-                                                  const double* __restrict__ rpart, Scalars* sc) {
+                                                  const double* __restrict__ rpart, int nrpart,
+                                                  Scalars* sc) {
     if (sc->done) return;
     __shared__ double smem[12 * 4];
     __shared__ int stop_s;
@@ -721,7 +756,7 @@ __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ par
         // ||r||_1 / ||L||_inf < tol, algebraicconnectivity.py:243).  The kernels of this
         // iteration that already ran only touched w / Aw / scratch, never x or theta.
         double rv[1] = {0.0};
-        for (int b = threadIdx.x; b < nblk; b += 256) rv[0] += rpart[b];
+        for (int b = threadIdx.x; b < nrpart; b += 256) rv[0] += rpart[b];
         block_sum<1>(rv, smem);
         if (threadIdx.x == 0) {
             const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
@@ -782,33 +817,46 @@ __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ par
     sc->coef[2] = coef[2];
 }
 
-// x, p, Ax, Ap ← Ritz update;  r = Ax - theta x;  partial ||r||_1
-__global__ __launch_bounds__(256) void k_update(double* __restrict__ x, const double* __restrict__ w,
-                                                double* __restrict__ p, double* __restrict__ Ax,
-                                                const double* __restrict__ Aw,
-                                                double* __restrict__ Ap, double* __restrict__ r,
-                                                int n, double* __restrict__ rpart, Scalars* sc) {
+// x, p, Ax, Ap ← Ritz update;  r = Ax - theta x;  partial ||r||_1 — laid out on the scan
+// partition (block b = nodes [1024 b, 1024 b + 1024), thread t = 4 consecutive nodes) so the
+// same launch also emits the forward block composites of the NEXT tridiagonal solve.
+__global__ __launch_bounds__(kScanThreads) void k_update_fwd_agg(
+    double* __restrict__ x, const double* __restrict__ w, double* __restrict__ p,
+    double* __restrict__ Ax, const double* __restrict__ Aw, double* __restrict__ Ap,
+    double* __restrict__ r, const double* __restrict__ l, int n, double* __restrict__ rpart,
+    Aff* __restrict__ agg_f, Scalars* sc) {
     if (sc->done) return;
-    __shared__ double smem[4];
+    __shared__ Aff smem[kScanThreads];
+    __shared__ double red[4];
     const double c0 = sc->coef[0], c1 = sc->coef[1], c2 = sc->coef[2];
     const double mu = sc->mu, theta = sc->theta;
+    const int i0 = blockIdx.x * kScanBlock + threadIdx.x * kScanElems;
     double v[1] = {0.0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        double wi = w[i] - mu;
-        double pn = c1 * wi + c2 * p[i];
-        double apn = c1 * Aw[i] + c2 * Ap[i];
-        double xn = c0 * x[i] + pn;
-        double axn = c0 * Ax[i] + apn;
-        x[i] = xn;
-        p[i] = pn;
-        Ax[i] = axn;
-        Ap[i] = apn;
-        double ri = axn - theta * xn;
-        r[i] = ri;
-        v[0] += fabs(ri);
+    Aff t{1.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < kScanElems; ++e) {
+        const int i = i0 + e;
+        if (i < n) {
+            const double wi = w[i] - mu;
+            const double pn = c1 * wi + c2 * p[i];
+            const double apn = c1 * Aw[i] + c2 * Ap[i];
+            const double xn = c0 * x[i] + pn;
+            const double axn = c0 * Ax[i] + apn;
+            x[i] = xn;
+            p[i] = pn;
+            Ax[i] = axn;
+            Ap[i] = apn;
+            const double ri = axn - theta * xn;
+            r[i] = ri;
+            v[0] += fabs(ri);
+            t = compose(t, Aff{i > 0 ? -l[i - 1] : 0.0, ri});
+        }
     }
-    block_sum<1>(v, smem);
+    block_sum<1>(v, red);
     if (threadIdx.x == 0) rpart[blockIdx.x] = v[0];
+    __syncthreads();
+    Aff inc = block_scan_aff(t, smem, threadIdx.x);
+    if (threadIdx.x == kScanThreads - 1) agg_f[blockIdx.x] = inc;
 }
 
 // end-of-replay convergence word for the host (same test k_rr_solve makes at the start of the
@@ -1191,25 +1239,25 @@ void launch_topk(const double* x, int64_t m, int64_t k, double* mask, TopkState*
 
 void launch_iteration(cslam_mac* mac, hipStream_t st) {
     const int n = mac->n;
-    const unsigned gs = (unsigned)mac->nscan, gr = (unsigned)mac->nred;
+    const unsigned gs = (unsigned)mac->nscan;
     const unsigned gn = (unsigned)((n + 255) / 256);
-    // w = M^-1 r  (forward + backward affine scans, 3 launches), psum = per-block sums of w
-    hipLaunchKernelGGL(k_fwd_agg, dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l, n,
-                       mac->agg_f, mac->sc);
+    // w = M^-1 r: the forward composites were emitted by the previous update (or the
+    // bootstrap); forward apply + backward composites, backward apply (psum = block sums of w)
     hipLaunchKernelGGL(k_fwd_apply_bwd_agg, dim3(gs), dim3(kScanThreads), 0, st, mac->r, mac->l,
                        mac->invd, n, mac->agg_f, mac->y, mac->agg_b, mac->sc);
     hipLaunchKernelGGL(k_bwd_apply, dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l, mac->invd,
                        n, mac->agg_b, mac->w, mac->psum, mac->sc);
-    // Aw = L w
-    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
-                       mac->w, mac->Aw, n, mac->sc);
-    hipLaunchKernelGGL(k_dots, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax, mac->Aw,
-                       mac->Ap, n, mac->psum, mac->nscan, 1, mac->partial, mac->sc);
+    // Aw = L w + the 12 Gram dot products
+    hipLaunchKernelGGL(k_spmv_dots, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
+                       mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan,
+                       mac->partial, mac->sc);
     // convergence test of the previous update + 3x3 Rayleigh-Ritz
-    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                       mac->nscan, 1, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_update, dim3(gr), dim3(256), 0, st, mac->x, mac->w, mac->p, mac->Ax,
-                       mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, (int)gn, mac->psum,
+                       mac->nscan, 1, n, mac->rpart, mac->nscan, mac->sc);
+    // Ritz update + residual + forward composites of the next solve
+    hipLaunchKernelGGL(k_update_fwd_agg, dim3(gs), dim3(kScanThreads), 0, st, mac->x, mac->w,
+                       mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n, mac->rpart, mac->agg_f,
+                       mac->sc);
 }
 
 int build_graph(cslam_mac* mac) {
@@ -1217,7 +1265,7 @@ int build_graph(cslam_mac* mac) {
     hipGraph_t g = nullptr;
     CSLAM_HIP_TRY(hipStreamBeginCapture(mac->stream, hipStreamCaptureModeThreadLocal));
     for (int it = 0; it < kIterPerGraph; ++it) launch_iteration(mac, mac->stream);
-    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, mac->stream, mac->rpart, mac->nred,
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, mac->stream, mac->rpart, mac->nscan,
                        mac->sc);
     CSLAM_HIP_TRY(hipStreamEndCapture(mac->stream, &g));
     CSLAM_HIP_TRY(hipGraphInstantiate(&mac->graph, g, nullptr, nullptr, 0));
@@ -1266,10 +1314,11 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
     hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
                        mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
     hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                       mac->nscan, 0, n, (const double*)nullptr, mac->sc);
-    hipLaunchKernelGGL(k_update, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
-                       mac->Ax, mac->Aw, mac->Ap, mac->r, n, mac->rpart, mac->sc);
-    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nred, mac->sc);
+                       mac->nscan, 0, n, (const double*)nullptr, 0, mac->sc);
+    hipLaunchKernelGGL(k_update_fwd_agg, dim3((unsigned)mac->nscan), dim3(kScanThreads), 0, st,
+                       mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n,
+                       mac->rpart, mac->agg_f, mac->sc);
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nscan, mac->sc);
     CSLAM_HIP_TRY(hipGetLastError());
     CSLAM_TRY(build_graph(mac));
     Scalars h;
@@ -1399,6 +1448,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     mac->nscan = (n + kScanBlock - 1) / kScanBlock;
     mac->nfact = (n + kFactBlock - 1) / kFactBlock;
     mac->nred = std::min(kRedBlocksMax, (n + 255) / 256);
+    const int npartial = std::max(mac->nred, (n + 255) / 256);
 
     int rc = CSLAM_OK;
     auto A = [&](int r) {
@@ -1426,8 +1476,8 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->agg_b, mac->nscan));
     A(dev_alloc(&mac->agg_m, mac->nfact));
     A(dev_alloc(&mac->psum, mac->nscan));
-    A(dev_alloc(&mac->partial, (size_t)mac->nred * 12));
-    A(dev_alloc(&mac->rpart, mac->nred));
+    A(dev_alloc(&mac->partial, (size_t)npartial * 12));
+    A(dev_alloc(&mac->rpart, std::max(mac->nred, mac->nscan)));
     A(dev_alloc(&mac->sc, 1));
     A(dev_alloc(&mac->wvec, n_cand));
     A(dev_alloc(&mac->gvec, n_cand));
