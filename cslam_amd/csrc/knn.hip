@@ -649,7 +649,8 @@ __global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ 
 //   from that XCD's L2).
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kGemmPitch = 20;
+constexpr int kGemmKb = 1;                         // k-blocks (of 16 floats) per LDS stage (2 measured 5 % slower)
+constexpr int kGemmPitch = kGemmKb * 16 + 4;       // 36 floats: conflict-free ds_read_b128
 
 __global__ __launch_bounds__(256, 2) void k_gemm32(const float* __restrict__ X, int64_t xs,
                                                    int64_t n, int dp,
@@ -673,16 +674,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm32(const float* __restrict__ X, 
     const int wr = wave >> 1, wc = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
     const int nkb = dp >> 4;
+    const int nstep = (nkb + kGemmKb - 1) / kGemmKb;
 
-    // staging assignment: thread → (tile row tid/2, float4 columns 2*(tid&1), +1)
+    // staging assignment: thread → tile row tid/2, half of the stage row's kGemmKb*4 float4
+    constexpr int kF4 = kGemmKb * 2;  // float4 per thread per operand per stage
     const int srow = tid >> 1;
-    const int sc4 = (tid & 1) * 2;
+    const int sc4 = (tid & 1) * kF4;
     int64_t xrow = (int64_t)rowblk * 128 + srow;
     if (xrow >= n) xrow = n - 1;  // clamp: results of clamped rows are not stored
-    const f32x4* xg = reinterpret_cast<const f32x4*>(X + xrow * xs) + sc4;
-    const f32x4* qg = reinterpret_cast<const f32x4*>(Q + (int64_t)(colblk * 128 + srow) * dp) + sc4;
-    float* as_w = &As[0][srow * kGemmPitch + sc4 * 4];
-    float* bs_w = &Bs[0][srow * kGemmPitch + sc4 * 4];
+    const f32x4* xg = reinterpret_cast<const f32x4*>(X + xrow * xs);
+    const f32x4* qg = reinterpret_cast<const f32x4*>(Q + (int64_t)(colblk * 128 + srow) * dp);
+    const int woff = srow * kGemmPitch + sc4 * 4;
+    const int nf4 = dp >> 2;  // float4 per row
 
     f32x16 acc[2][2], tot[2][2];
 #pragma unroll
@@ -695,59 +698,87 @@ __global__ __launch_bounds__(256, 2) void k_gemm32(const float* __restrict__ X, 
                 tot[i][j][e] = 0.f;
             }
 
-    f32x4 pa0 = xg[0], pa1 = xg[1], pb0 = qg[0], pb1 = qg[1];
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        // stage step kb
-        *reinterpret_cast<f32x4*>(as_w + buf * 128 * kGemmPitch) = pa0;
-        *reinterpret_cast<f32x4*>(as_w + buf * 128 * kGemmPitch + 4) = pa1;
-        *reinterpret_cast<f32x4*>(bs_w + buf * 128 * kGemmPitch) = pb0;
-        *reinterpret_cast<f32x4*>(bs_w + buf * 128 * kGemmPitch + 4) = pb1;
-        if (kb + 1 < nkb) {  // prefetch step kb+1 while this one is consumed
-            pa0 = xg[(kb + 1) * 4];
-            pa1 = xg[(kb + 1) * 4 + 1];
-            pb0 = qg[(kb + 1) * 4];
-            pb1 = qg[(kb + 1) * 4 + 1];
+    // operands travel HBM/L2 → registers THREE stages ahead (one stage = 2048 MFMA cycles per
+    // wave, less than a loaded HBM round trip) → LDS (double buffered) → MFMA
+    f32x4 pa[3][kF4], pb[3][kF4];
+    auto fetch = [&](f32x4 (&da)[kF4], f32x4 (&db)[kF4], int step) {
+        if (step >= nstep) step = nstep - 1;  // past the end: harmless re-read, branch-free
+#pragma unroll
+        for (int c = 0; c < kF4; ++c) {
+            int f = step * (kGemmKb * 4) + sc4 + c;  // float4 index in the row
+            if (f >= nf4) f = nf4 - 1;               // ragged last stage: value unused (kb >= nkb)
+            da[c] = xg[f];
+            db[c] = qg[f];
+        }
+    };
+    auto consume = [&](const f32x4 (&sa)[kF4], const f32x4 (&sb)[kF4], int step) {
+        const int buf = step & 1;
+#pragma unroll
+        for (int c = 0; c < kF4; ++c) {
+            *reinterpret_cast<f32x4*>(&As[buf][woff + 4 * c]) = sa[c];
+            *reinterpret_cast<f32x4*>(&Bs[buf][woff + 4 * c]) = sb[c];
         }
         __syncthreads();
-        f32x4 a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* ap = &As[buf][(wr * 64 + i * 32 + r32) * kGemmPitch + 4 * h];
-            a0[i] = *reinterpret_cast<const f32x4*>(ap);
-            a1[i] = *reinterpret_cast<const f32x4*>(ap + 8);
-            const float* bp = &Bs[buf][(wc * 64 + i * 32 + r32) * kGemmPitch + 4 * h];
-            b0[i] = *reinterpret_cast<const f32x4*>(bp);
-            b1[i] = *reinterpret_cast<const f32x4*>(bp + 8);
-        }
+        for (int kk = 0; kk < kGemmKb; ++kk) {
+            const int kb = step * kGemmKb + kk;
+            if (kb < nkb) {
+                f32x4 a0[2], a1[2], b0[2], b1[2];
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j4], b0[j][j4],
-                                                                     acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j4], b1[j][j4],
-                                                                     acc[i][j], 0, 0, 0);
-        }
-        if ((kb + 1) % kChunkKb == 0 || kb + 1 == nkb) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    tot[i][j] = tot[i][j] + acc[i][j];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int i = 0; i < 2; ++i) {
+                    const float* ap =
+                        &As[buf][(wr * 64 + i * 32 + r32) * kGemmPitch + kk * 16 + 4 * h];
+                    a0[i] = *reinterpret_cast<const f32x4*>(ap);
+                    a1[i] = *reinterpret_cast<const f32x4*>(ap + 8);
+                    const float* bp =
+                        &Bs[buf][(wc * 64 + i * 32 + r32) * kGemmPitch + kk * 16 + 4 * h];
+                    b0[i] = *reinterpret_cast<const f32x4*>(bp);
+                    b1[i] = *reinterpret_cast<const f32x4*>(bp + 8);
                 }
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a0[i][j4], b0[j][j4], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a1[i][j4], b1[j][j4], acc[i][j], 0, 0, 0);
+                }
+                if ((kb + 1) % kChunkKb == 0 || kb + 1 == nkb) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            tot[i][j] = tot[i][j] + acc[i][j];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                        }
+                }
+            }
         }
-        // the double buffer makes one barrier per step enough: step kb+1 writes the other
-        // buffer, and nobody can reach step kb+2's writes before passing step kb+1's barrier
+        // the double buffer makes one barrier per stage enough: stage s+1 writes the other
+        // buffer, and nobody reaches stage s+2's writes before passing stage s+1's barrier
+    };
+    fetch(pa[0], pb[0], 0);
+    fetch(pa[1], pb[1], 1);
+    fetch(pa[2], pb[2], 2);
+    int step = 0;
+    for (; step + 3 <= nstep; step += 3) {
+        consume(pa[0], pb[0], step);
+        fetch(pa[0], pb[0], step + 3);
+        consume(pa[1], pb[1], step + 1);
+        fetch(pa[1], pb[1], step + 4);
+        consume(pa[2], pb[2], step + 2);
+        fetch(pa[2], pb[2], step + 5);
     }
+    if (step < nstep) consume(pa[0], pb[0], step);
+    if (step + 1 < nstep) consume(pa[1], pb[1], step + 1);
     // epilogue: lane holds D[row = (e&3) + 8*(e>>2) + 4h][col = r32] of every 32x32 tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
