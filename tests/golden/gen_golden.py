@@ -376,6 +376,43 @@ def gen_lcsm():
 
 
 # ----------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] ("cfg1"): 2 robots x 1000 keyframes x 128-d, interleaved
+# add_local / add_other, threshold 0.0, one fixed edge, select_candidates(100)
+# ----------------------------------------------------------------------------------------------
+def cfg1_descriptors():
+    d = np.random.RandomState(0).rand(2, 1000, 128).astype(np.float32)
+    return d / np.linalg.norm(d, axis=2, keepdims=True)
+
+
+def gen_cfg1():
+    def params():
+        return {"robot_id": 0, "max_nb_robots": 2, "frontend.sensor_type": "stereo",
+                "frontend.similarity_threshold": 0.0, "frontend.nb_best_matches": 10,
+                "frontend.intra_loop_min_inbetween_keyframes": 10,
+                "frontend.enable_sparsification": True,
+                "evaluation.enable_sparsification_comparison": False}
+    desc = cfg1_descriptors()
+    l = LoopClosureSparseMatching(params(), FakeNode())
+    l.local_nnsm.device = torch.device("cpu")
+    for m in l.other_robots_nnsm.values():
+        m.device = torch.device("cpu")
+    matches = []
+    for kf in range(1000):
+        ms = l.add_local_global_descriptor(desc[0, kf], kf)
+        matches.append([[int(x[3]), float(x[4])] for x in ms])
+        m = l.add_other_robot_global_descriptor(GlobalDescriptor(kf, 1, desc[1, kf].tolist()))
+        matches.append(None if m is None else [int(m[1]), float(m[4])])
+    cand = {str(k): float(v.weight) for k, v in l.candidate_selector.candidate_edges.items()}
+    l.candidate_selector.add_fixed_edge(EdgeInterRobot(0, 999, 1, 999, 1.0))
+    with contextlib.redirect_stdout(io.StringIO()):
+        sel = l.select_candidates(100, {0: True, 1: True})
+    with open(os.path.join(HERE, "cfg1_ref.json"), "w") as f:
+        json.dump(dict(params=params(), matches=matches, candidates=cand,
+                       selected=_edge_list(sel)), f)
+    print("cfg1_ref.json: candidates", len(cand), "selected", len(sel))
+
+
+# ----------------------------------------------------------------------------------------------
 # Broker (cslam/broker.py): vertex covers of selections, bipartite (Hopcroft-Karp + Koenig via
 # networkx) and multi-robot (networkx local-ratio 2-approximation), and the random dialog
 # ----------------------------------------------------------------------------------------------
@@ -417,3 +454,4 @@ if __name__ == "__main__":
     gen_acm()
     gen_lcsm()
     gen_broker()
+    gen_cfg1()
