@@ -168,3 +168,110 @@ def test_single_rank_degenerates_to_local_insert():
     x = np.random.RandomState(0).rand(3, DIM).astype(np.float32)
     assert sh.step(torch.from_numpy(x), [0, 1, 2]) == []
     assert sh.matcher.size == 3 and sh.is_broker()
+
+
+# ------------------------------------------------------------------------------------------------
+# the same protocol on the real HIP pools: 4 robot shards as 4 threads of one process sharing
+# one GPU (every shard owns its own cslam_pool handle), all-gathers done through a barrier
+# ------------------------------------------------------------------------------------------------
+class ThreadComm(object):
+    """all_gather among `world` threads of this process (test double of TorchDistComm)."""
+
+    class Shared(object):
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.torch = torch
+        self.shared = shared
+        self.rank = rank
+        self.world = shared.world
+
+    def all_gather(self, t):
+        sh = self.shared
+        sh.slots[self.rank] = t
+        sh.barrier.wait()
+        out = torch.stack([s.to(t.device) for s in sh.slots], dim=0)
+        sh.barrier.wait()
+        return out
+
+
+@pytest.mark.gpu
+def test_sharded_protocol_on_hip_pools_matches_sequential_reference(gpu):
+    import threading
+    from cslam_amd.multi_robot import HipPoolMatcher, ShardedLoopClosureMatching
+    world, steps = 4, 10
+    blocks = make_blocks(world, steps, seed=3)
+    shared = ThreadComm.Shared(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            sh = ShardedLoopClosureMatching(ThreadComm(shared, rank), HipPoolMatcher(DIM), THR,
+                                            max_block=MAXB)
+            for t in range(steps):
+                x, kfs = blocks[(t, rank)]
+                sh.step(torch.from_numpy(x).cuda(), kfs)
+            results[rank] = {k: float(v.weight)
+                             for k, v in sh.candidate_selector.candidate_edges.items()}
+        except Exception as e:  # surface worker failures in the main thread
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    assert not errors, errors
+
+    # sequential reference semantics with the oracle on the same blocks
+    union, _ = _sequential_reference_with(blocks, world, steps)
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for k in union:
+            assert abs(results[r][k] - union[k]) <= 1e-7
+        assert results[r] == results[0]
+
+
+def _sequential_reference_with(blocks, world, steps):
+    from cslam_amd.algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
+                                                               EdgeInterRobot)
+    local = [OracleMatcher() for _ in range(world)]
+    mirror = [[OracleMatcher() for _ in range(world)] for _ in range(world)]
+    sel = [AlgebraicConnectivityMaximization(r, world) for r in range(world)]
+
+    def best(m, x):
+        if m.size == 0:
+            return None, None
+        idx, sim = m.search_best(torch.from_numpy(x[None, :]), 0, m.size)
+        return m.keyframes[int(idx[0])], float(sim[0])
+
+    for t in range(steps):
+        for r in range(world):
+            x, kfs = blocks[(t, r)]
+            for s in range(world):
+                if s == r:
+                    continue
+                for i, kf in enumerate(kfs):
+                    mirror[s][r].add_rows(torch.from_numpy(x[i:i + 1]), [kf])
+                    kb, sim = best(local[s], x[i])
+                    if kb is not None and sim >= THR:
+                        sel[s].add_match(EdgeInterRobot(s, kb, r, kf, sim))
+        for r in range(world):
+            x, kfs = blocks[(t, r)]
+            for i, kf in enumerate(kfs):
+                local[r].add_rows(torch.from_numpy(x[i:i + 1]), [kf])
+                for s in range(world):
+                    if s == r:
+                        continue
+                    kb, sim = best(mirror[r][s], x[i])
+                    if kb is not None and sim >= THR:
+                        sel[r].add_match(EdgeInterRobot(r, kf, s, kb, sim))
+    union = {}
+    for r in range(world):
+        for k, e in sel[r].candidate_edges.items():
+            union[k] = max(union.get(k, -1.0), float(e.weight))
+    return union, [m.size for m in local]
