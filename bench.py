@@ -93,23 +93,42 @@ def main():
                                            ctypes.c_void_p(os_.data_ptr()),
                                            ctypes.c_void_p(stream)))
 
-    def step():
+    # N > 1: the all-gather of step t+1's descriptors runs on RCCL's stream while the scan of
+    # step t runs on the compute stream (two landing buffers); every step still does one
+    # all-gather and one search, and both are inside the timed region.
+    landing = [gathered, torch.empty_like(gathered)] if world > 1 else [gathered]
+    pending = [None]
+
+    def issue_gather(slot):
+        pending[0] = dist.all_gather_into_tensor(landing[slot], new_local, async_op=True)
+
+    def step(t):
         if world > 1:
-            dist.all_gather_into_tensor(gathered, new_local)
-        search(gathered, 1, out_idx, out_sim)
+            pending[0].wait()          # compute stream waits for the descriptors of step t
+            issue_gather((t + 1) & 1)  # step t+1's exchange overlaps this step's scan
+            search(landing[t & 1], 1, out_idx, out_sim)
+        else:
+            search(gathered, 1, out_idx, out_sim)
 
     def fence():
         if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if world > 1:
+        issue_gather(0)
+    for t in range(args.warmup):
+        step(t)
     fence()
     _lib.check(L.cslam_pool_profile_begin(pool.handle, args.steps))
+    if world > 1:
+        issue_gather(0)
+        fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for t in range(args.steps):
+        step(t)
     fence()
     dt = time.perf_counter() - t0
     scan_ms = ctypes.c_double()
@@ -153,7 +172,8 @@ def main():
                                "descriptors per step, best match (k=1) in the pool",
                    "keyframes_per_gpu": N, "dim": D, "queries_per_step_per_gpu": gathered_rows,
                    "k": 1, "parallelism": f"robot-per-gpu x{world}"
-                                          + (" + RCCL all-gather of new descriptors" if world > 1 else "")},
+                                          + (" + RCCL all-gather of new descriptors, overlapped "
+                                             "with the previous step's scan" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": "k_scan<T=1,S=8,U=4,G=4>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_kernel_ms": scan_ms.value,

@@ -22,6 +22,7 @@
 // only polls a `done` word between replays.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -92,24 +93,42 @@ __global__ __launch_bounds__(256) void k_edge_weights(const double* __restrict__
     ew_cand[k] = (wk > tol) ? wk * cw[k] : 0.0;  // mac.py:72-73
 }
 
-// a_i = L_ii, b_i = L_{i,i+1} inside a fixed odometry chain (else 0), ||L||_inf
+// a_i = L_ii, b_i = L_{i,i+1} inside a fixed odometry chain (else 0), ||L||_inf — and the
+// ACTIVE adjacency of L(w): the slots of row i whose edge weight is non-zero, moved (order kept)
+// to the front of the row's slot range as (cnbr, caw) pairs, cnt[i] of them (pub[]: see below).  Only a few
+// thousand of the 200k candidates carry weight at any time, so the mat-vec of every solver
+// iteration reads ~5x fewer slots; the skipped terms are exact zeros, the row sums unchanged.
 __global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_ptr,
                                               const int32_t* __restrict__ adj_nbr,
                                               const int32_t* __restrict__ adj_eid,
                                               const double* __restrict__ ew,
                                               const uint8_t* __restrict__ link, int n,
                                               double* __restrict__ a, double* __restrict__ b,
-                                              Scalars* sc) {
+                                              int32_t* __restrict__ cnbr, double* __restrict__ caw,
+                                              int32_t* __restrict__ cnt, uint8_t* __restrict__ pub,
+                                              int row_regs, Scalars* sc) {
     int i = blockIdx.x * 256 + threadIdx.x;
     double ai = 0.0;
     if (i < n) {
         double bi = 0.0;
         const bool lk = (i + 1 < n) && link[i];
-        for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) {
-            double wgt = ew[adj_eid[e]];
+        const int e0 = adj_ptr[i];
+        int o = e0;
+        for (int e = e0; e < adj_ptr[i + 1]; ++e) {
+            const double wgt = ew[adj_eid[e]];
+            const int nb = adj_nbr[e];
             ai += wgt;
-            if (lk && adj_nbr[e] == i + 1) bi -= wgt;
+            if (lk && nb == i + 1) bi -= wgt;
+            if (wgt != 0.0) {
+                // the persistent solver takes w of chain neighbours (i +- 1, among the first
+                // row_regs entries) from registers; any other referenced node must publish its w
+                if ((nb != i - 1 && nb != i + 1) || o - e0 >= row_regs) pub[nb] = 1;
+                cnbr[o] = nb;
+                caw[o] = wgt;
+                ++o;
+            }
         }
+        cnt[i] = o - e0;
         a[i] = ai;
         if (i + 1 < n) b[i] = bi;
     }
@@ -387,27 +406,28 @@ __global__ __launch_bounds__(kScanThreads) void k_bwd_apply(const double* __rest
 // --------------------------------------------------------------------------------------------
 // y = L x   (one thread per row; the working set lives in L2)
 // --------------------------------------------------------------------------------------------
-// aw[slot] = ew[adj_eid[slot]]: edge weights gathered once per solve into adjacency order, so
-// the mat-vec reads (nbr, weight) pairs contiguously instead of chasing edge ids
-__global__ __launch_bounds__(256) void k_adj_weights(const int32_t* __restrict__ adj_eid,
-                                                     const double* __restrict__ ew, int64_t nslot,
-                                                     double* __restrict__ aw) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < nslot) aw[e] = ew[adj_eid[e]];
+// row i of L(w) v over the active adjacency (k_diag): sum of caw * (v_i - v_nbr), slot order
+__device__ inline double laplacian_row(int i, const int32_t* __restrict__ adj_ptr,
+                                       const int32_t* __restrict__ cnt,
+                                       const int32_t* __restrict__ cnbr,
+                                       const double* __restrict__ caw,
+                                       const double* __restrict__ v, double vi) {
+    const int e0 = adj_ptr[i], e1 = e0 + cnt[i];
+    double acc = 0.0;
+    for (int e = e0; e < e1; ++e) acc += caw[e] * (vi - v[cnbr[e]]);
+    return acc;
 }
 
 __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_ptr,
-                                              const int32_t* __restrict__ adj_nbr,
-                                              const double* __restrict__ aw,
+                                              const int32_t* __restrict__ cnt,
+                                              const int32_t* __restrict__ cnbr,
+                                              const double* __restrict__ caw,
                                               const double* __restrict__ x,
                                               double* __restrict__ y, int n, const Scalars* sc) {
     if (sc->done) return;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double xi = x[i];
-    double acc = 0.0;
-    for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) acc += aw[e] * (xi - x[adj_nbr[e]]);
-    y[i] = acc;
+    y[i] = laplacian_row(i, adj_ptr, cnt, cnbr, caw, x, x[i]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -465,8 +485,9 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
 // need row i of every vector, so the mat-vec result never has to be re-read) — one launch less
 // per iteration.  partial[] has one slot per block of 256 rows.
 __global__ __launch_bounds__(256) void k_spmv_dots(const int32_t* __restrict__ adj_ptr,
-                                                   const int32_t* __restrict__ adj_nbr,
-                                                   const double* __restrict__ aw,
+                                                   const int32_t* __restrict__ cnt,
+                                                   const int32_t* __restrict__ cnbr,
+                                                   const double* __restrict__ caw,
                                                    const double* __restrict__ x,
                                                    const double* __restrict__ w,
                                                    const double* __restrict__ p,
@@ -485,8 +506,7 @@ __global__ __launch_bounds__(256) void k_spmv_dots(const int32_t* __restrict__ a
     for (int q = 0; q < 12; ++q) v[q] = 0.0;
     if (i < n) {
         const double wraw = w[i];
-        double acc = 0.0;
-        for (int e = adj_ptr[i]; e < adj_ptr[i + 1]; ++e) acc += aw[e] * (wraw - w[adj_nbr[e]]);
+        const double acc = laplacian_row(i, adj_ptr, cnt, cnbr, caw, w, wraw);
         Aw[i] = acc;
         const double xi = x[i], wi = wraw - mu, pi = p[i];
         const double axi = Ax[i], api = Ap[i];
@@ -743,6 +763,29 @@ __device__ inline bool rr_try(const double (&GB)[3][3], const double (&GA)[3][3]
     return true;
 }
 
+// one Rayleigh-Ritz step from the 12 Gram sums (layout of k_dots); false = breakdown
+__device__ inline bool rr_step(const double (&g)[12], double (&coef)[3], double& theta) {
+    const double GB[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
+    const double GA[3][3] = {{g[6], g[7], g[8]}, {g[7], g[9], g[10]}, {g[8], g[10], g[11]}};
+    if (!(GB[0][0] > 1e-280)) return false;  // x vanished
+    // basis members with a non-negligible norm relative to x
+    const bool has_w = GB[1][1] > 1e-280 && GB[1][1] > 1e-60 * GB[0][0];
+    const bool has_p = GB[2][2] > 1e-280 && GB[2][2] > 1e-60 * GB[0][0];
+    coef[0] = coef[1] = coef[2] = 0.0;
+    bool ok = false;
+    if (has_w && has_p) ok = rr_try<3, 0, 1, 2>(GB, GA, coef, theta);
+    if (!ok && has_w) ok = rr_try<2, 0, 1, 2>(GB, GA, coef, theta);   // p dropped (restart)
+    if (!ok && has_p && !has_w) ok = rr_try<2, 0, 2, 1>(GB, GA, coef, theta);
+    if (!ok) ok = rr_try<1, 0, 1, 2>(GB, GA, coef, theta);
+    if (!ok) return false;
+    if (coef[0] < 0.0) {  // keep the orientation of x
+        coef[0] = -coef[0];
+        coef[1] = -coef[1];
+        coef[2] = -coef[2];
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ partial, int nblk,
                                                   const double* __restrict__ psum, int nscan,
                                                   int use_mu, int n,
@@ -786,30 +829,10 @@ __global__ __launch_bounds__(256) void k_rr_solve(const double* __restrict__ par
     const double mu = use_mu ? mean_from_psum(psum, nscan, n) : 0.0;
     if (threadIdx.x != 0) return;
     sc->mu = mu;
-    const double GB[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
-    const double GA[3][3] = {{g[6], g[7], g[8]}, {g[7], g[9], g[10]}, {g[8], g[10], g[11]}};
-    if (!(GB[0][0] > 1e-280)) {  // x vanished: breakdown
+    double coef[3], theta = sc->theta;
+    if (!rr_step(g, coef, theta)) {
         sc->done = 2;
         return;
-    }
-    // basis members with a non-negligible norm relative to x
-    const bool has_w = GB[1][1] > 1e-280 && GB[1][1] > 1e-60 * GB[0][0];
-    const bool has_p = GB[2][2] > 1e-280 && GB[2][2] > 1e-60 * GB[0][0];
-    double coef[3] = {0.0, 0.0, 0.0};
-    double theta = sc->theta;
-    bool ok = false;
-    if (has_w && has_p) ok = rr_try<3, 0, 1, 2>(GB, GA, coef, theta);
-    if (!ok && has_w) ok = rr_try<2, 0, 1, 2>(GB, GA, coef, theta);   // p dropped (restart)
-    if (!ok && has_p && !has_w) ok = rr_try<2, 0, 2, 1>(GB, GA, coef, theta);
-    if (!ok) ok = rr_try<1, 0, 1, 2>(GB, GA, coef, theta);
-    if (!ok) {
-        sc->done = 2;
-        return;
-    }
-    if (coef[0] < 0.0) {  // keep the orientation of x
-        coef[0] = -coef[0];
-        coef[1] = -coef[1];
-        coef[2] = -coef[2];
     }
     sc->theta = theta;
     sc->coef[0] = coef[0];
@@ -857,6 +880,565 @@ __global__ __launch_bounds__(kScanThreads) void k_update_fwd_agg(
     __syncthreads();
     Aff inc = block_scan_aff(t, smem, threadIdx.x);
     if (threadIdx.x == kScanThreads - 1) agg_f[blockIdx.x] = inc;
+}
+
+// --------------------------------------------------------------------------------------------
+// Persistent LOBPCG: the whole iteration loop in ONE launch.
+//
+// The solver is latency-bound (a 50k-node pose graph is ~2 MB of state): as five graph-captured
+// launches an iteration costs ~40 us, of which the arithmetic is a few us.  Here a small grid
+// (<= 64 workgroups of 512 threads, all co-resident) keeps x, p, Ax, Ap, r of its nodes in
+// REGISTERS for the whole solve and exchanges only what crosses workgroups, four times per
+// iteration — one per true global dependency: forward-sweep carries (+ the residual norm),
+// backward-sweep carries, w of the mat-vec neighbours (+ its mean), the 12 Gram sums.
+//
+// Exchange = STAMPED SLOTS, no barrier and no fence: every exchanged double travels in a 16-byte
+// slot {value, stamp} written with ONE agent-scope (sc1, write-through) 16-byte store and read
+// with ONE agent-scope 16-byte load; a reader polls the slots it needs until the stamp is the
+// current iteration's.  Each slot array is double-buffered by iteration parity: a slot of
+// iteration k+2 is written only after its writer has read every workgroup's k+1 values, which
+// those published after they had finished reading iteration k.  One such all-to-all round costs
+// ~1.6 us at 25 workgroups against ~4 us for two fenced counter barriers + loads, and — no
+// acquire fence — the read-only operands (adjacency, LDL^T factors) stay in L1/L2
+// (tools/exchange_probe.hip, tools/barrier_probe.hip).  Stamps grow monotonically over the
+// life of the handle, so slots never need clearing between solves.
+//
+// Every workgroup reduces the published partials itself (same data, same order → bit-identical
+// decisions everywhere) and every thread runs the 3x3 Rayleigh-Ritz redundantly: nothing is
+// broadcast.  Partition: workgroup b owns nodes [b*512*E, (b+1)*512*E), thread t the E
+// consecutive nodes from (b*512 + t)*E.
+// Exit: all workgroups leave on the same iteration (converged / max_iters / NaN).  A poll that
+// is not satisfied within kSpinCap reads (the CUs are held by someone else's kernel) ends the
+// workgroup with done = 4; the others then time out too, and the host redoes the solve with
+// the graph-captured launches from the same x.
+// --------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// cross-lane primitives on the VALU (DPP) instead of ds_bpermute: the eight waves of a
+// persistent workgroup share ONE LDS pipe, and `__shfl` of a double is two LDS crossbar ops —
+// 12 butterfly sums per wave made the reductions, not the arithmetic, the cost of an iteration.
+// --------------------------------------------------------------------------------------------
+constexpr int kDppQuadSwap1 = 0xB1;      // quad_perm [1,0,3,2]
+constexpr int kDppQuadSwap2 = 0x4E;      // quad_perm [2,3,0,1]
+constexpr int kDppRowShr = 0x110;        // + n: lane i reads lane i-n of its row of 16
+constexpr int kDppWaveShl1 = 0x130;      // lane i reads lane i+1 across the whole wave
+constexpr int kDppWaveShr1 = 0x138;      // lane i reads lane i-1 across the whole wave
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowBcast15 = 0x142;    // lane 15 of each row → the next row
+constexpr int kDppRowBcast31 = 0x143;    // lane 31 → rows 2 and 3
+
+// lanes without a valid source (or masked out by ROW_MASK) get `fill`
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline double dpp_mov(double v, double fill) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL,
+                                               ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL,
+                                               ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_bcast_dyn(double v, int lane /* wave-uniform */) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ inline double lane_bcast(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// sum over the 64 lanes in a fixed order, returned in every lane
+__device__ inline double wave_sum_dpp(double v) {
+    v += dpp_mov<kDppQuadSwap1>(v, 0.0);
+    v += dpp_mov<kDppQuadSwap2>(v, 0.0);
+    v += dpp_mov<kDppRowHalfMirror>(v, 0.0);
+    v += dpp_mov<kDppRowMirror>(v, 0.0);         // every lane: the sum of its row of 16
+    v += dpp_mov<kDppRowBcast15, 0xA>(v, 0.0);   // rows 1, 3 += rows 0, 2
+    v += dpp_mov<kDppRowBcast31, 0xC>(v, 0.0);   // rows 2, 3 += rows 0..1
+    return lane_bcast(v, 63);
+}
+// inclusive scan of Aff composites in ascending lane order (lane i: elements 0..i composed)
+__device__ inline Aff wave_scan_aff(Aff v) {
+#define CSLAM_SCAN_STEP(CTRL, MASK)                                       \
+    {                                                                     \
+        const Aff o{dpp_mov<CTRL, MASK>(v.m, 1.0), dpp_mov<CTRL, MASK>(v.c, 0.0)}; \
+        v = compose(o, v);                                                \
+    }
+    CSLAM_SCAN_STEP(kDppRowShr + 1, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 2, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 4, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 8, 0xF)
+    CSLAM_SCAN_STEP(kDppRowBcast15, 0xA)
+    CSLAM_SCAN_STEP(kDppRowBcast31, 0xC)
+#undef CSLAM_SCAN_STEP
+    return v;
+}
+// the value of lane 63 - i (one LDS crossbar op per dword)
+__device__ inline double wave_reverse(double v) {
+    const int idx = (63 - (int)(threadIdx.x & 63)) << 2;
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(idx, __double2hiint(v)),
+                            __builtin_amdgcn_ds_bpermute(idx, __double2loint(v)));
+}
+
+constexpr int kPT = 512;
+constexpr int kPWaves = kPT / 64;
+constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
+constexpr int kPMaxElems = 8;
+constexpr int kPRowRegs = 3;     // adjacency entries of a row gathered in the first batch
+constexpr long kSpinCap = 1L << 20;
+
+typedef double d2 __attribute__((ext_vector_type(2)));  // {value, stamp}
+
+struct PArgs {
+    const int32_t *adj_ptr, *cnt, *cnbr;
+    const uint8_t* pub;
+    const double *caw, *l, *invd;
+    double *x, *p, *Ax, *Ap, *r;
+    d2* xs;           // stamped exchange slots (kSlot* offsets, in slots)
+    int64_t wstride;  // slots per parity of the per-node w array
+    double stamp0;  // stamp of iteration 0 of this solve
+    Scalars* sc;
+    int n;
+    long long* prof;  // optional [16]: per-phase 100 MHz ticks of workgroup 0 (CSLAM_MAC_PROF)
+};
+
+// slot offsets inside the exchange buffer; every array is [2 parities][...]
+constexpr int kSlotXfM = 0, kSlotXfC = 2 * kPMaxBlocks, kSlotXbM = 4 * kPMaxBlocks,
+              kSlotXbC = 6 * kPMaxBlocks, kSlotPs = 8 * kPMaxBlocks, kSlotRp = 10 * kPMaxBlocks,
+              kSlotPt = 12 * kPMaxBlocks /* [2][12][kPMaxBlocks] */,
+              kSlotW = 36 * kPMaxBlocks /* [2][wstride] */;
+
+// One buffer_load/store_dwordx4 with sc1 (agent scope: served by / written through to the
+// memory side, past the per-XCD L2) per slot.  Plain buffer intrinsics, not volatile or atomic
+// accesses: the compiler keeps independent loads in flight together and never waits on a store.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t SlotBuf;
+constexpr int kAuxSc1 = 16;
+__device__ inline SlotBuf slot_buffer(d2* base, int64_t nslots) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nslots * 16), 0x00020000);
+}
+__device__ inline d2 ld_slot(SlotBuf rs, int slot) {
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, slot * 16, 0, kAuxSc1));
+}
+__device__ inline void st_slot(SlotBuf rs, int slot, double v, double stamp) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, d2{v, stamp}), rs, slot * 16, 0,
+                                           kAuxSc1);
+}
+__device__ inline double poll_slot(SlotBuf rs, int slot, d2 v, double stamp, int& ok) {
+    long spins = 0;
+    while (v.y != stamp) {
+        if (++spins > kSpinCap) {
+            ok = 0;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = ld_slot(rs, slot);
+    }
+    return v.x;
+}
+
+// scan of one Aff per thread across the kPT-thread workgroup in sweep order (REV: descending
+// thread id): excl = composite of everything before this thread, total = the whole workgroup's
+template <bool REV>
+__device__ inline void block_scan_p(Aff t, Aff* swave /* [kPWaves] */, Aff& excl, Aff& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // in sweep order: lane i holds sweep position i of its wave
+    Aff v = REV ? Aff{wave_reverse(t.m), wave_reverse(t.c)} : t;
+    v = wave_scan_aff(v);
+    Aff ex{dpp_mov<kDppWaveShr1>(v.m, 1.0), dpp_mov<kDppWaveShr1>(v.c, 0.0)};
+    if (lane == 63) swave[wave] = v;
+    __syncthreads();
+    Aff pre{1.0, 0.0};
+    total = Aff{1.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < kPWaves; ++q) {
+        const int k = REV ? kPWaves - 1 - q : q;
+        const Aff sk = swave[k];
+        if (REV ? (k > wave) : (k < wave)) pre = compose(pre, sk);
+        total = compose(total, sk);
+    }
+    ex = compose(pre, ex);
+    excl = REV ? Aff{wave_reverse(ex.m), wave_reverse(ex.c)} : ex;
+}
+
+// value entering workgroup b in sweep order: the composites of the workgroups before it applied
+// to 0.  One wave: lane j polls workgroup j's composite (both slots in flight together), then a
+// shuffle scan over the 64 lanes.
+template <bool REV>
+__device__ inline double fold_incoming(SlotBuf rs, int slot_m, int slot_c, int nb, int b,
+                                       double stamp, int& ok) {
+    const int lane = threadIdx.x & 63;
+    const int j = REV ? 63 - lane : lane;  // workgroup this lane polls
+    Aff v{1.0, 0.0};
+    if (j < nb) {
+        const d2 vm = ld_slot(rs, slot_m + j), vc = ld_slot(rs, slot_c + j);
+        v.m = poll_slot(rs, slot_m + j, vm, stamp, ok);
+        v.c = poll_slot(rs, slot_c + j, vc, stamp, ok);
+    }
+    // sweep order ascending in lanes: for the backward sweep lane j takes workgroup 63 - j
+    // (lanes of absent workgroups hold the identity, wherever they sit)
+    v = wave_scan_aff(v);
+    const int src = REV ? 63 - (b + 1) : b - 1;
+    const bool none = REV ? (b + 1 >= nb) : (b == 0);
+    const double r = lane_bcast_dyn(v.c, src & 63);
+    return none ? 0.0 : r;
+}
+
+// sum over workgroups of one published double per workgroup (lane j of the calling wave polls
+// workgroup j; every lane returns the sum)
+__device__ inline double fold_sum(SlotBuf rs, int slot, int nb, double stamp, int& ok) {
+    const int lane = threadIdx.x & 63;
+    double v = 0.0;
+    if (lane < nb) v = poll_slot(rs, slot + lane, ld_slot(rs, slot + lane), stamp, ok);
+    return wave_sum_dpp(v);
+}
+
+// workgroup reduction of NV values (LDS [NV][kPWaves]); thread q < NV returns value q
+template <int NV>
+__device__ inline double block_sum_p(const double (&v)[NV], double* sred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const double s = wave_sum_dpp(v[q]);
+        if (lane == 0) sred[q * kPWaves + wave] = s;
+    }
+    __syncthreads();
+    double o = 0.0;
+    if ((int)threadIdx.x < NV) {
+#pragma unroll
+        for (int k = 0; k < kPWaves; ++k) o += sred[threadIdx.x * kPWaves + k];
+    }
+    return o;
+}
+
+#define PTICK(k)                               \
+    do {                                       \
+        const long long now_ = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0; \
+        pacc[k] += now_ - plast;               \
+        plast = now_;                          \
+    } while (0)
+
+template <int E>
+__global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
+    __shared__ Aff swave[kPWaves];
+    __shared__ double sred[12 * kPWaves];
+    __shared__ double s_vin, s_res, s_vinb, s_mu, s_g[12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int n = a.n;
+    const int i0 = (b * kPT + tid) * E;
+    Scalars* sc = a.sc;
+    const SlotBuf xb = slot_buffer(a.xs, kSlotW + 2 * a.wstride);
+    const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
+    const double tol = sc->tol;
+    const int max_iters = sc->max_iters;
+    double theta = sc->theta;
+    int iters = sc->iters;
+    int done = 0;
+    int ok = 1;
+    double res = 0.0;
+
+    double x[E], p[E], Ax[E], Ap[E], r[E], lprev[E], lcur[E], idv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = i0 + e;
+        const bool in = i < n;
+        x[e] = in ? a.x[i] : 0.0;
+        p[e] = in ? a.p[i] : 0.0;
+        Ax[e] = in ? a.Ax[i] : 0.0;
+        Ap[e] = in ? a.Ap[i] : 0.0;
+        r[e] = in ? a.r[i] : 0.0;
+        lprev[e] = (in && i > 0) ? a.l[i - 1] : 0.0;
+        lcur[e] = (in && i + 1 < n) ? a.l[i] : 0.0;
+        idv[e] = in ? a.invd[i] : 0.0;
+    }
+    // nodes past n carry zeros everywhere: their sweep elements are {0, 0}, harmless in both
+    // directions (they come last in the forward sweep; node n-1 ignores its successor)
+
+    // composites of the first forward sweep + ||r||_1 of the bootstrap → iteration 0's inputs
+    Aff excl_f, tot;
+    {
+        Aff t{1.0, 0.0};
+        double rs[1] = {0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            t = compose(t, Aff{-lprev[e], r[e]});
+            rs[0] += fabs(r[e]);
+        }
+        block_scan_p<false>(t, swave, excl_f, tot);
+        const double bs = block_sum_p<1>(rs, sred);
+        if (tid == 0) {
+            st_slot(xb, kSlotXfM + b, tot.m, a.stamp0);
+            st_slot(xb, kSlotXfC + b, tot.c, a.stamp0);
+            st_slot(xb, kSlotRp + b, bs, a.stamp0);
+        }
+    }
+    // the first kPRowRegs active adjacency entries of every row stay in registers for the
+    // whole solve (a pose-graph row is two chain links + the odd loop closure).  Where an
+    // entry's neighbour is i-1 / i+1 and lives in this thread or the adjacent lane, its w comes
+    // from registers (kLeft / kRight); only the rest is gathered from the published slots
+    // (kRemote), and only nodes somebody gathers are published (pub[] from k_diag + the first /
+    // last node of every wave).
+    enum { kNone = 0, kRemote = 1, kLeft = 2, kRight = 3 };
+    int e0[E], cn[E], nbr[E][kPRowRegs], kind[E][kPRowRegs];
+    double rw[E][kPRowRegs];
+    bool publish[E];
+    bool any_remote = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = i0 + e;
+        e0[e] = i < n ? a.adj_ptr[i] : 0;
+        cn[e] = i < n ? a.cnt[i] : 0;
+        publish[e] = i < n && (a.pub[i] != 0 || (e == 0 && lane == 0) || (e == E - 1 && lane == 63));
+#pragma unroll
+        for (int q = 0; q < kPRowRegs; ++q) {
+            const bool has = q < cn[e];
+            nbr[e][q] = has ? a.cnbr[e0[e] + q] : 0;
+            rw[e][q] = has ? a.caw[e0[e] + q] : 0.0;
+            int kd = kNone;
+            if (has) {
+                kd = kRemote;
+                if (nbr[e][q] == i - 1 && !(e == 0 && lane == 0)) kd = kLeft;
+                if (nbr[e][q] == i + 1 && !(e == E - 1 && lane == 63)) kd = kRight;
+            }
+            kind[e][q] = kd;
+            any_remote |= kd == kRemote;
+        }
+        any_remote |= cn[e] > kPRowRegs;
+    }
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const long long pstart = plast;
+
+    for (int k = 0;; ++k) {
+        const double stamp = a.stamp0 + (double)k;
+        const int par = k & 1;
+        const int xo = par * kPMaxBlocks;
+
+        // ---- A: residual norm + forward carries of every workgroup (published by D / above)
+        if (wave == 0) {
+            const double v = fold_incoming<false>(xb, kSlotXfM + xo, kSlotXfC + xo, nb, b, stamp, ok);
+            if (lane == 0) s_vin = v;
+        } else if (wave == 1) {
+            const double v = fold_sum(xb, kSlotRp + xo, nb, stamp, ok);
+            if (lane == 0) s_res = v;
+        }
+        if (!__syncthreads_and(ok)) {
+            done = 4;
+            break;
+        }
+        PTICK(0);
+        // convergence test of the last Ritz update (networkx criterion, see k_rr_solve)
+        res = s_res / lnorm;
+        iters += 1;
+        if (res < tol)
+            done = 1;
+        else if (iters >= max_iters)
+            done = 3;
+        if (!(res == res)) done = 2;
+        if (done) break;
+
+        // forward apply, backward composites
+        double y[E];
+        Aff excl_b;
+        {
+            double v = excl_f.m * s_vin + excl_f.c;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                v = r[e] - lprev[e] * v;
+                y[e] = v;
+            }
+            Aff t{1.0, 0.0};
+#pragma unroll
+            for (int e = E - 1; e >= 0; --e) t = compose(t, Aff{-lcur[e], y[e] * idv[e]});
+            block_scan_p<true>(t, swave, excl_b, tot);
+            if (tid == 0) {
+                st_slot(xb, kSlotXbM + xo + b, tot.m, stamp);
+                st_slot(xb, kSlotXbC + xo + b, tot.c, stamp);
+            }
+        }
+        PTICK(1);
+
+        // ---- B: backward carries → w (published per node: the mat-vec gathers neighbours)
+        if (wave == 0) {
+            const double v = fold_incoming<true>(xb, kSlotXbM + xo, kSlotXbC + xo, nb, b, stamp, ok);
+            if (lane == 0) s_vinb = v;
+        }
+        if (!__syncthreads_and(ok)) {
+            done = 4;
+            break;
+        }
+        PTICK(2);
+        double w[E];
+        const int wslot = kSlotW + par * (int)a.wstride;
+        {
+            double v = excl_b.m * s_vinb + excl_b.c;
+            double ws[1] = {0.0};
+#pragma unroll
+            for (int e = E - 1; e >= 0; --e) {
+                v = y[e] * idv[e] - lcur[e] * v;
+                w[e] = v;
+                ws[0] += v;
+                if (publish[e]) st_slot(xb, wslot + i0 + e, v, stamp);
+            }
+            const double bs = block_sum_p<1>(ws, sred);
+            if (tid == 0) st_slot(xb, kSlotPs + xo + b, bs, stamp);
+        }
+        PTICK(3);
+
+        // ---- C: Aw = L w (gathering the neighbours' w), Gram partials of S = [x, w - mu, p]
+        double Aw[E];
+        {
+            // remote entries first: all their slot loads in flight together
+            d2 gv[E][kPRowRegs];
+            if (any_remote) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int q = 0; q < kPRowRegs; ++q)
+                        if (kind[e][q] == kRemote) gv[e][q] = ld_slot(xb, wslot + nbr[e][q]);
+            }
+            if (wave == 0) {
+                const double v = fold_sum(xb, kSlotPs + xo, nb, stamp, ok);
+                if (lane == 0) s_mu = v / (double)n;
+            }
+            // chain neighbours held by the adjacent lanes
+            const double w_before = dpp_mov<kDppWaveShr1>(w[E - 1], 0.0);
+            const double w_after = dpp_mov<kDppWaveShl1>(w[0], 0.0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double wl = e > 0 ? w[e > 0 ? e - 1 : 0] : w_before;
+                const double wr = e < E - 1 ? w[e < E - 1 ? e + 1 : 0] : w_after;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < kPRowRegs; ++q) {
+                    const int kd = kind[e][q];
+                    double wn = kd == kLeft ? wl : wr;
+                    if (kd == kRemote) wn = poll_slot(xb, wslot + nbr[e][q], gv[e][q], stamp, ok);
+                    if (kd != kNone) acc += rw[e][q] * (w[e] - wn);
+                }
+                for (int q = kPRowRegs; q < cn[e]; ++q) {  // long rows: the rest, one by one
+                    const int sp = wslot + a.cnbr[e0[e] + q];
+                    const double wn = poll_slot(xb, sp, ld_slot(xb, sp), stamp, ok);
+                    acc += a.caw[e0[e] + q] * (w[e] - wn);
+                }
+                Aw[e] = acc;
+            }
+        }
+        if (!__syncthreads_and(ok)) {
+            done = 4;
+            break;
+        }
+        PTICK(4);
+        const double mu = s_mu;
+        {
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (i0 + e < n) {
+                    const double xi = x[e], wi = w[e] - mu, pi = p[e], acc = Aw[e];
+                    g[0] += xi * xi;
+                    g[1] += xi * wi;
+                    g[2] += xi * pi;
+                    g[3] += wi * wi;
+                    g[4] += wi * pi;
+                    g[5] += pi * pi;
+                    g[6] += xi * Ax[e];
+                    g[7] += xi * acc;
+                    g[8] += xi * Ap[e];
+                    g[9] += wi * acc;
+                    g[10] += wi * Ap[e];
+                    g[11] += pi * Ap[e];
+                }
+            }
+            const double bs = block_sum_p<12>(g, sred);
+            if (tid < 12) st_slot(xb, kSlotPt + (par * 12 + tid) * kPMaxBlocks + b, bs, stamp);
+        }
+        PTICK(5);
+
+        // ---- D: Gram sums (wave v folds sums v and v + 8), Rayleigh-Ritz in every thread,
+        //         Ritz update, residual, forward composites of the next iteration
+        {
+            const int s0 = kSlotPt + (par * 12 + wave) * kPMaxBlocks + lane;
+            const int s1 = s0 + 8 * kPMaxBlocks;
+            const bool two = wave < 4;
+            d2 v0{0.0, stamp}, v1{0.0, stamp};
+            if (lane < nb) {
+                v0 = ld_slot(xb, s0);
+                if (two) v1 = ld_slot(xb, s1);
+            }
+            double g0 = 0.0, g1 = 0.0;
+            if (lane < nb) {
+                g0 = poll_slot(xb, s0, v0, stamp, ok);
+                if (two) g1 = poll_slot(xb, s1, v1, stamp, ok);
+            }
+            g0 = wave_sum_dpp(g0);
+            g1 = wave_sum_dpp(g1);
+            if (lane == 0) {
+                s_g[wave] = g0;
+                if (two) s_g[wave + 8] = g1;
+            }
+        }
+        if (!__syncthreads_and(ok)) {
+            done = 4;
+            break;
+        }
+        PTICK(6);
+        {
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = s_g[q];
+            double coef[3];
+            if (!rr_step(g, coef, theta)) {
+                done = 2;
+                break;
+            }
+            Aff t{1.0, 0.0};
+            double rs[1] = {0.0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double wi = (i0 + e < n) ? w[e] - mu : 0.0;
+                const double pn = coef[1] * wi + coef[2] * p[e];
+                const double apn = coef[1] * Aw[e] + coef[2] * Ap[e];
+                const double xn = coef[0] * x[e] + pn;
+                const double axn = coef[0] * Ax[e] + apn;
+                x[e] = xn;
+                p[e] = pn;
+                Ax[e] = axn;
+                Ap[e] = apn;
+                const double ri = axn - theta * xn;
+                r[e] = ri;
+                rs[0] += fabs(ri);
+                t = compose(t, Aff{-lprev[e], ri});
+            }
+            block_scan_p<false>(t, swave, excl_f, tot);
+            const double bs = block_sum_p<1>(rs, sred);
+            if (tid == 0) {
+                const int xn = (par ^ 1) * kPMaxBlocks;
+                st_slot(xb, kSlotXfM + xn + b, tot.m, stamp + 1.0);
+                st_slot(xb, kSlotXfC + xn + b, tot.c, stamp + 1.0);
+                st_slot(xb, kSlotRp + xn + b, bs, stamp + 1.0);
+            }
+        }
+        PTICK(7);
+    }
+
+    if (done != 4) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (i0 + e < n) a.x[i0 + e] = x[e];
+    }
+    if (b == 0 && tid == 0 && a.prof) {
+        for (int q = 0; q < 8; ++q) a.prof[q] += pacc[q];
+        a.prof[8] += (long long)__builtin_amdgcn_s_memtime() - pstart;
+        a.prof[9] += wall_clock64();  // unused
+    }
+    if (b == 0 && tid == 0) {
+        sc->theta = theta;
+        sc->res = res;
+        sc->lnorm = lnorm;
+        sc->iters = iters;
+        sc->done = done;
+    }
 }
 
 // end-of-replay convergence word for the host (same test k_rr_solve makes at the start of the
@@ -1152,6 +1734,8 @@ struct cslam_mac {
     hipStream_t stream = nullptr;
     // device
     int32_t *adj_ptr = nullptr, *adj_nbr = nullptr, *adj_eid = nullptr;
+    int32_t *cnbr = nullptr, *cnt = nullptr;  // active adjacency of the current L(w) (k_diag)
+    uint8_t* pub = nullptr;                   // nodes whose w some other thread gathers
     int32_t *ci_d = nullptr, *cj_d = nullptr;
     double *cw_d = nullptr, *ew = nullptr, *aw = nullptr;
     int64_t nslot = 0;
@@ -1164,6 +1748,13 @@ struct cslam_mac {
     int nfact = 0;
     double *psum = nullptr, *partial = nullptr, *rpart = nullptr;
     Scalars* sc = nullptr;
+    d2* xslots = nullptr;      // stamped exchange slots of the persistent solver (PArgs)
+    int64_t wstride = 0;
+    double stamp_next = 1.0;   // slots start zeroed; stamps only ever grow
+    long long* prof = nullptr;
+    int persist_elems = 0;    // nodes per thread of the persistent solver (0 = graph path)
+    int persist_blocks = 0;
+    int64_t persist_fallbacks = 0;
     double *wvec = nullptr, *gvec = nullptr, *svec = nullptr;  // FW state [m]
     TopkState* tk_state = nullptr;
     unsigned int* tk_hist = nullptr;
@@ -1248,8 +1839,8 @@ void launch_iteration(cslam_mac* mac, hipStream_t st) {
     hipLaunchKernelGGL(k_bwd_apply, dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l, mac->invd,
                        n, mac->agg_b, mac->w, mac->psum, mac->sc);
     // Aw = L w + the 12 Gram dot products
-    hipLaunchKernelGGL(k_spmv_dots, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
-                       mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan,
+    hipLaunchKernelGGL(k_spmv_dots, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->cnt, mac->cnbr,
+                       mac->aw, mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan,
                        mac->partial, mac->sc);
     // convergence test of the previous update + 3x3 Rayleigh-Ritz
     hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, (int)gn, mac->psum,
@@ -1296,40 +1887,81 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
     init.fw_gap_tol = keep.fw_gap_tol;
     init.fw_alpha = keep.fw_alpha;
     CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->pub, 0, (size_t)n, st));
     hipLaunchKernelGGL(k_diag, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->adj_eid,
-                       mac->ew, mac->link, n, mac->a, mac->b, mac->sc);
+                       mac->ew, mac->link, n, mac->a, mac->b, mac->cnbr, mac->aw, mac->cnt, mac->pub,
+                       kPRowRegs, mac->sc);
     hipLaunchKernelGGL(k_fact_agg, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
                        mac->b, n, mac->agg_m);
     hipLaunchKernelGGL(k_fact_apply, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
                        mac->b, n, mac->agg_m, mac->l, mac->invd, mac->sc);
     // bootstrap: Ax = L x, 1x1 Rayleigh-Ritz (w = p = 0), r = Ax - theta x
-    CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
-    CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
-    CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
-    CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
-    hipLaunchKernelGGL(k_adj_weights, dim3((unsigned)((mac->nslot + 255) / 256)), dim3(256), 0, st,
-                       mac->adj_eid, mac->ew, mac->nslot, mac->aw);
-    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->aw,
-                       mac->x, mac->Ax, n, mac->sc);
-    hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
-                       mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
-    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                       mac->nscan, 0, n, (const double*)nullptr, 0, mac->sc);
-    hipLaunchKernelGGL(k_update_fwd_agg, dim3((unsigned)mac->nscan), dim3(kScanThreads), 0, st,
-                       mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n,
-                       mac->rpart, mac->agg_f, mac->sc);
-    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nscan, mac->sc);
-    CSLAM_HIP_TRY(hipGetLastError());
-    CSLAM_TRY(build_graph(mac));
+    auto bootstrap = [&]() -> int {
+        CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
+        CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
+        CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
+        CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
+        hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->cnt, mac->cnbr,
+                           mac->aw, mac->x, mac->Ax, n, mac->sc);
+        hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w,
+                           mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0,
+                           mac->partial, mac->sc);
+        hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
+                           mac->nscan, 0, n, (const double*)nullptr, 0, mac->sc);
+        hipLaunchKernelGGL(k_update_fwd_agg, dim3((unsigned)mac->nscan), dim3(kScanThreads), 0, st,
+                           mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n,
+                           mac->rpart, mac->agg_f, mac->sc);
+        hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nscan,
+                           mac->sc);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    };
     Scalars h;
-    while (true) {
+    auto poll = [&]() -> int {
         CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
         CSLAM_HIP_TRY(hipStreamSynchronize(st));
         if (h.factor_bad)
             return fail(CSLAM_E_DISCONNECTED,
                         "tridiagonal pivot <= 0: L(w) has an isolated node (disconnected graph)");
-        if (h.done) break;
+        return CSLAM_OK;
+    };
+    CSLAM_TRY(bootstrap());
+    CSLAM_TRY(poll());
+    if (!h.done && mac->persist_elems > 0) {
+        // the whole iteration loop in one launch (k_lobpcg_persistent)
+        PArgs pa{};
+        pa.adj_ptr = mac->adj_ptr; pa.cnt = mac->cnt; pa.cnbr = mac->cnbr; pa.caw = mac->aw; pa.pub = mac->pub;
+        pa.l = mac->l; pa.invd = mac->invd;
+        pa.x = mac->x; pa.p = mac->p; pa.Ax = mac->Ax; pa.Ap = mac->Ap; pa.r = mac->r;
+        pa.xs = mac->xslots;
+        pa.wstride = mac->wstride;
+        pa.stamp0 = mac->stamp_next;
+        pa.sc = mac->sc; pa.n = n; pa.prof = mac->prof;
+        mac->stamp_next += (double)(kMaxIters + 4);
+        const dim3 grid((unsigned)mac->persist_blocks), block(kPT);
+        switch (mac->persist_elems) {
+            case 1: hipLaunchKernelGGL((k_lobpcg_persistent<1>), grid, block, 0, st, pa); break;
+            case 2: hipLaunchKernelGGL((k_lobpcg_persistent<2>), grid, block, 0, st, pa); break;
+            case 4: hipLaunchKernelGGL((k_lobpcg_persistent<4>), grid, block, 0, st, pa); break;
+            default: hipLaunchKernelGGL((k_lobpcg_persistent<8>), grid, block, 0, st, pa); break;
+        }
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_TRY(poll());
+        if (h.done == 4) {
+            // a barrier was not met in time (the CUs were held by someone else's kernel):
+            // x is untouched, redo the bootstrap and iterate with ordinary launches
+            mac->persist_fallbacks += 1;
+            const int zero = 0;
+            CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->done, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+            CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->iters, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+            CSLAM_TRY(bootstrap());
+            CSLAM_TRY(poll());
+        }
+    }
+    if (!h.done) CSLAM_TRY(build_graph(mac));
+    while (!h.done) {
         CSLAM_HIP_TRY(hipGraphLaunch(mac->graph, st));
+        CSLAM_TRY(poll());
     }
     mac->spmv_count += h.iters;
     if (iters_out) *iters_out = h.iters;
@@ -1449,6 +2081,27 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     mac->nfact = (n + kFactBlock - 1) / kFactBlock;
     mac->nred = std::min(kRedBlocksMax, (n + 255) / 256);
     const int npartial = std::max(mac->nred, (n + 255) / 256);
+    // persistent solver: smallest nodes-per-thread whose grid stays within kPersistBlocks
+    // workgroups (barrier cost grows with the grid, tools/barrier_probe.hip); graphs too big for
+    // kPMaxElems nodes per thread iterate with graph-captured launches instead
+    {
+        int want_blocks = kPMaxBlocks, force_e = 0;
+        if (const char* ev = getenv("CSLAM_MAC_PERSIST_BLOCKS")) want_blocks = atoi(ev);
+        if (const char* ev = getenv("CSLAM_MAC_PERSIST_ELEMS")) force_e = atoi(ev);
+        want_blocks = std::max(1, std::min(want_blocks, kPMaxBlocks));
+        mac->persist_elems = 0;
+        for (int e = 1; e <= kPMaxElems; e *= 2) {
+            const int nbk = (int)(((int64_t)n + (int64_t)kPT * e - 1) / ((int64_t)kPT * e));
+            const bool fits = force_e ? (e == force_e && nbk <= kPMaxBlocks) : nbk <= want_blocks;
+            if (fits) {
+                mac->persist_elems = e;
+                mac->persist_blocks = nbk;
+                break;
+            }
+        }
+        if (const char* ev = getenv("CSLAM_MAC_PERSISTENT"))
+            if (atoi(ev) == 0) mac->persist_elems = 0;
+    }
 
     int rc = CSLAM_OK;
     auto A = [&](int r) {
@@ -1468,6 +2121,9 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->ew, E));
     mac->nslot = (int64_t)nbr.size();
     A(dev_alloc(&mac->aw, nbr.size()));
+    A(dev_alloc(&mac->cnbr, nbr.size()));
+    A(dev_alloc(&mac->cnt, n));
+    A(dev_alloc(&mac->pub, n));
     A(dev_alloc(&mac->link, n));
     for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
                        &mac->Aw, &mac->Ap, &mac->r, &mac->y})
@@ -1479,6 +2135,15 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->partial, (size_t)npartial * 12));
     A(dev_alloc(&mac->rpart, std::max(mac->nred, mac->nscan)));
     A(dev_alloc(&mac->sc, 1));
+    mac->wstride = ((int64_t)n + 63) / 64 * 64;
+    const size_t nslots = (size_t)(kSlotW + 2 * mac->wstride);
+    A(dev_alloc(&mac->xslots, nslots));
+    if (mac->xslots && hipMemset(mac->xslots, 0, nslots * sizeof(d2)) != hipSuccess)
+        A(fail(CSLAM_E_HIP, "mac_create: memset failed"));
+    if (getenv("CSLAM_MAC_PROF")) {
+        A(dev_alloc(&mac->prof, 16));
+        if (mac->prof) (void)hipMemset(mac->prof, 0, 16 * sizeof(long long));
+    }
     A(dev_alloc(&mac->wvec, n_cand));
     A(dev_alloc(&mac->gvec, n_cand));
     A(dev_alloc(&mac->svec, n_cand));
@@ -1524,14 +2189,24 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
     if (!mac) return CSLAM_OK;
     (void)hipSetDevice(mac->device);
     if (mac->stream) (void)hipStreamSynchronize(mac->stream);
+    if (mac->prof) {
+        long long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpy(h, mac->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char* nm[9] = {"pollA", "A", "pollB", "B", "gatherC", "C", "pollD", "D", "total"};
+            fprintf(stderr, "[cslam mac prof] iters %lld; s_memtime ticks/iter:", (long long)mac->spmv_count);
+            for (int k = 0; k < 9; ++k)
+                fprintf(stderr, " %s %.1f", nm[k], h[k] / (double)std::max<int64_t>(1, mac->spmv_count));
+            fprintf(stderr, "\n");
+        }
+    }
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
     for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
-                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->link,
+                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->cnbr, (void*)mac->cnt, (void*)mac->pub, (void*)mac->link,
                     (void*)mac->a, (void*)mac->b,
                     (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
                     (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
                     (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->agg_m, (void*)mac->psum, (void*)mac->partial,
-                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->wvec, (void*)mac->gvec,
+                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->xslots, (void*)mac->prof, (void*)mac->wvec, (void*)mac->gvec,
                     (void*)mac->svec, (void*)mac->tk_state, (void*)mac->tk_hist, (void*)mac->tk_lkey,
                     (void*)mac->tk_lidx})
         if (p) (void)hipFree(p);
