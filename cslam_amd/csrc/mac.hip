@@ -9,17 +9,29 @@
 //                       directions; built once in cslam_mac_create)
 //   ew[E]               current weight of every edge: fixed weight, or w_k*c_k (0 when
 //                       w_k <= tol)  ← the only thing L(w) changes between FW iterations
-//   L(w) is never materialised on the device: y = L x is y_i = sum_e ew[e] (x_i - x_nbr(e)),
-//   rows summed in adjacency order (deterministic, no atomics).
+//   L(w) is never materialised on the device.  Per solve k_diag derives its ACTIVE form — chain
+//   weights chl/chr to the index neighbours, and the non-zero loop-closure entries compacted to
+//   the front of each row — and y = L x is y_i = chl_i (x_i - x_{i-1}) + chr_i (x_i - x_{i+1}) +
+//   sum_e caw[e] (x_i - x_nbr(e)), rows summed in a fixed order (deterministic, no atomics).
 //
 // Fiedler pair: LOBPCG with one vector (3x3 Rayleigh-Ritz over {x, w, p}), constraint x ⟂ 1,
 // preconditioner M = tridiag(L(w)) restricted to the fixed odometry chains (SPD because L is
 // diagonally dominant; parameter-free).  M is factored LDL^T once per solve; M z = r is two
-// first-order linear recurrences = two parallel affine scans.  ~150 iterations at cfg3 scale
-// (vs ~3e5 SpMVs for Jacobi-PCG TraceMIN).  Converged to a TIGHTER residual than
-// the reference's tol so the eigenvector (hence the gradient ranking) is at least as accurate.
-// One iteration = 8 small kernels captured in a hipGraph (16 iterations per replay); the host
-// only polls a `done` word between replays.
+// first-order linear recurrences = two parallel affine scans.  ~270 iterations cold at cfg3
+// scale, ~80 warm (vs ~3e5 SpMVs for Jacobi-PCG TraceMIN).  Converged to a
+// TIGHTER residual than the reference's tol so the eigenvector (hence the gradient ranking) is
+// at least as accurate.
+//
+// Two ways to run the iteration:
+//   * k_lobpcg_persistent (graphs up to 64*512*8 nodes): bootstrap + the whole loop in ONE
+//     launch of <= 64 co-resident workgroups, solver state in registers, four stamped-slot
+//     exchanges per iteration (see the comment at the kernel) — ~15 us per iteration;
+//   * five small kernels per iteration captured in a hipGraph (16 iterations per replay, the
+//     host polls a `done` word between replays) — ~40 us per iteration; larger graphs, and the
+//     fallback if the persistent grid cannot meet.
+// The Frank-Wolfe loop (cslam_mac_fw_subset) queues all its iterations — solve, gradient,
+// exact top-k, duality gap, step — without a host round trip; stop flag and errors are sticky
+// words on the device that turn the rest of the queue into no-ops.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -54,6 +66,14 @@ struct Scalars {
     int max_iters;
     int fw_done;
     int factor_bad;
+    int fw_it;               // Frank-Wolfe iterations evaluated so far (asynchronous loop)
+    int err;                 // sticky: `done` code of the first failed solve of a sequence
+    long long total_iters;   // solver iterations since the counters were last reset
+};
+
+// survives the resets of Scalars: stamp of the persistent solver's next exchange round
+struct PersistState {
+    double stamp_next;
 };
 
 // --------------------------------------------------------------------------------------------
@@ -84,20 +104,40 @@ __device__ inline void block_sum(double (&v)[NV], double* smem /* [NV*4] */) {
 // --------------------------------------------------------------------------------------------
 // L(w) pieces
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_edge_weights(const double* __restrict__ w,
-                                                      const double* __restrict__ cw, int64_t m,
-                                                      double tol, double* __restrict__ ew_cand) {
-    int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= m) return;
-    double wk = w[k];
-    ew_cand[k] = (wk > tol) ? wk * cw[k] : 0.0;  // mac.py:72-73
+// first kernel of every solve: edge weights of L(w) from the device-resident w, the solver
+// fields of Scalars reset in place (the Frank-Wolfe fields and the sticky error stay), pub[]
+// cleared for k_diag
+__global__ __launch_bounds__(256) void k_prepare(const double* __restrict__ w,
+                                                 const double* __restrict__ cw, int64_t m,
+                                                 double tol, double* __restrict__ ew_cand,
+                                                 uint8_t* __restrict__ pub, int n, double solver_tol,
+                                                 int max_iters, Scalars* sc) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int64_t k = t; k < m; k += stride) {
+        const double wk = w[k];
+        ew_cand[k] = (wk > tol) ? wk * cw[k] : 0.0;  // mac.py:72-73
+    }
+    for (int64_t i = t; i < n; i += stride) pub[i] = 0;
+    if (t == 0) {
+        sc->tol = solver_tol;
+        sc->max_iters = max_iters;
+        sc->done = 0;
+        sc->iters = 0;
+        sc->lnorm_bits = 0ull;
+        sc->factor_bad = 0;
+        sc->res = 0.0;
+    }
 }
 
 // a_i = L_ii, b_i = L_{i,i+1} inside a fixed odometry chain (else 0), ||L||_inf — and the
-// ACTIVE adjacency of L(w): the slots of row i whose edge weight is non-zero, moved (order kept)
-// to the front of the row's slot range as (cnbr, caw) pairs, cnt[i] of them (pub[]: see below).  Only a few
-// thousand of the 200k candidates carry weight at any time, so the mat-vec of every solver
-// iteration reads ~5x fewer slots; the skipped terms are exact zeros, the row sums unchanged.
+// ACTIVE form of row i of L(w) that every solver iteration reads:
+//   chl[i], chr[i]   total weight of the edges to the index neighbours i-1 / i+1 (the odometry
+//                    chain: what almost every row of a pose graph consists of)
+//   (cnbr, caw)      the other entries whose edge weight is non-zero, moved (order kept) to the
+//                    front of the row's slot range, cnt[i] of them; pub[nbr] = 1 for their targets
+// Only a few thousand of the 200k candidates carry weight at any time, so the mat-vec reads
+// ~5x fewer slots; the skipped terms are exact zeros.
 __global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_ptr,
                                               const int32_t* __restrict__ adj_nbr,
                                               const int32_t* __restrict__ adj_eid,
@@ -105,8 +145,9 @@ __global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_pt
                                               const uint8_t* __restrict__ link, int n,
                                               double* __restrict__ a, double* __restrict__ b,
                                               int32_t* __restrict__ cnbr, double* __restrict__ caw,
-                                              int32_t* __restrict__ cnt, uint8_t* __restrict__ pub,
-                                              int row_regs, Scalars* sc) {
+                                              int32_t* __restrict__ cnt, double* __restrict__ chl,
+                                              double* __restrict__ chr, uint8_t* __restrict__ pub,
+                                              Scalars* sc) {
     int i = blockIdx.x * 256 + threadIdx.x;
     double ai = 0.0;
     if (i < n) {
@@ -114,21 +155,26 @@ __global__ __launch_bounds__(256) void k_diag(const int32_t* __restrict__ adj_pt
         const bool lk = (i + 1 < n) && link[i];
         const int e0 = adj_ptr[i];
         int o = e0;
+        double wl = 0.0, wr = 0.0;
         for (int e = e0; e < adj_ptr[i + 1]; ++e) {
             const double wgt = ew[adj_eid[e]];
             const int nb = adj_nbr[e];
             ai += wgt;
             if (lk && nb == i + 1) bi -= wgt;
-            if (wgt != 0.0) {
-                // the persistent solver takes w of chain neighbours (i +- 1, among the first
-                // row_regs entries) from registers; any other referenced node must publish its w
-                if ((nb != i - 1 && nb != i + 1) || o - e0 >= row_regs) pub[nb] = 1;
+            if (nb == i - 1) {
+                wl += wgt;
+            } else if (nb == i + 1) {
+                wr += wgt;
+            } else if (wgt != 0.0) {
+                pub[nb] = 1;  // somebody else gathers this node's w (persistent solver)
                 cnbr[o] = nb;
                 caw[o] = wgt;
                 ++o;
             }
         }
         cnt[i] = o - e0;
+        chl[i] = wl;
+        chr[i] = wr;
         a[i] = ai;
         if (i + 1 < n) b[i] = bi;
     }
@@ -406,28 +452,29 @@ __global__ __launch_bounds__(kScanThreads) void k_bwd_apply(const double* __rest
 // --------------------------------------------------------------------------------------------
 // y = L x   (one thread per row; the working set lives in L2)
 // --------------------------------------------------------------------------------------------
-// row i of L(w) v over the active adjacency (k_diag): sum of caw * (v_i - v_nbr), slot order
-__device__ inline double laplacian_row(int i, const int32_t* __restrict__ adj_ptr,
-                                       const int32_t* __restrict__ cnt,
-                                       const int32_t* __restrict__ cnbr,
-                                       const double* __restrict__ caw,
-                                       const double* __restrict__ v, double vi) {
-    const int e0 = adj_ptr[i], e1 = e0 + cnt[i];
+// row i of L(w) v in its active form (k_diag): chain terms first, then the other entries in
+// slot order
+struct RowsL {
+    const int32_t *adj_ptr, *cnt, *cnbr;
+    const double *caw, *chl, *chr;
+};
+__device__ inline double laplacian_row(int i, int n, const RowsL& L, const double* __restrict__ v,
+                                       double vi) {
     double acc = 0.0;
-    for (int e = e0; e < e1; ++e) acc += caw[e] * (vi - v[cnbr[e]]);
+    const double wl = L.chl[i], wr = L.chr[i];
+    if (wl != 0.0) acc += wl * (vi - v[i - 1]);
+    if (wr != 0.0) acc += wr * (vi - v[i + 1]);
+    const int e0 = L.adj_ptr[i], e1 = e0 + L.cnt[i];
+    for (int e = e0; e < e1; ++e) acc += L.caw[e] * (vi - v[L.cnbr[e]]);
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ adj_ptr,
-                                              const int32_t* __restrict__ cnt,
-                                              const int32_t* __restrict__ cnbr,
-                                              const double* __restrict__ caw,
-                                              const double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_spmv(RowsL L, const double* __restrict__ x,
                                               double* __restrict__ y, int n, const Scalars* sc) {
     if (sc->done) return;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    y[i] = laplacian_row(i, adj_ptr, cnt, cnbr, caw, x, x[i]);
+    y[i] = laplacian_row(i, n, L, x, x[i]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -484,10 +531,7 @@ __global__ __launch_bounds__(256) void k_dots(const double* __restrict__ x,
 // Aw = L w fused with the 12 Gram dot products (one thread per row: the products of row i only
 // need row i of every vector, so the mat-vec result never has to be re-read) — one launch less
 // per iteration.  partial[] has one slot per block of 256 rows.
-__global__ __launch_bounds__(256) void k_spmv_dots(const int32_t* __restrict__ adj_ptr,
-                                                   const int32_t* __restrict__ cnt,
-                                                   const int32_t* __restrict__ cnbr,
-                                                   const double* __restrict__ caw,
+__global__ __launch_bounds__(256) void k_spmv_dots(RowsL L,
                                                    const double* __restrict__ x,
                                                    const double* __restrict__ w,
                                                    const double* __restrict__ p,
@@ -506,7 +550,7 @@ __global__ __launch_bounds__(256) void k_spmv_dots(const int32_t* __restrict__ a
     for (int q = 0; q < 12; ++q) v[q] = 0.0;
     if (i < n) {
         const double wraw = w[i];
-        const double acc = laplacian_row(i, adj_ptr, cnt, cnbr, caw, w, wraw);
+        const double acc = laplacian_row(i, n, L, w, wraw);
         Aw[i] = acc;
         const double xi = x[i], wi = wraw - mu, pi = p[i];
         const double axi = Ax[i], api = Ap[i];
@@ -981,19 +1025,20 @@ constexpr int kPT = 512;
 constexpr int kPWaves = kPT / 64;
 constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
 constexpr int kPMaxElems = 8;
-constexpr int kPRowRegs = 3;     // adjacency entries of a row gathered in the first batch
+constexpr int kPRowRegs = 3;     // adjacency entries of a row kept in registers
+constexpr int kPRowTail = 2;     // further entries whose loads join the first batch
 constexpr long kSpinCap = 1L << 20;
 
 typedef double d2 __attribute__((ext_vector_type(2)));  // {value, stamp}
 
 struct PArgs {
-    const int32_t *adj_ptr, *cnt, *cnbr;
+    RowsL rows;
     const uint8_t* pub;
-    const double *caw, *l, *invd;
+    const double *l, *invd;
     double *x, *p, *Ax, *Ap, *r;
     d2* xs;           // stamped exchange slots (kSlot* offsets, in slots)
     int64_t wstride;  // slots per parity of the per-node w array
-    double stamp0;  // stamp of iteration 0 of this solve
+    PersistState* ps;  // stamp of this solve's first exchange round; advanced at exit
     Scalars* sc;
     int n;
     long long* prof;  // optional [16]: per-phase 100 MHz ticks of workgroup 0 (CSLAM_MAC_PROF)
@@ -1034,6 +1079,22 @@ __device__ inline double poll_slot(SlotBuf rs, int slot, d2 v, double stamp, int
     return v.x;
 }
 
+// two slots at once: a stale one is re-read while the other is checked, never one after the other
+__device__ inline void poll_slots2(SlotBuf rs, int s0, int s1, bool use1, d2& v0, d2& v1, double stamp,
+                                   int& ok) {
+    long spins = 0;
+    while (v0.y != stamp || (use1 && v1.y != stamp)) {
+        if (++spins > kSpinCap) {
+            ok = 0;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        const bool r0 = v0.y != stamp, r1 = use1 && v1.y != stamp;
+        if (r0) v0 = ld_slot(rs, s0);
+        if (r1) v1 = ld_slot(rs, s1);
+    }
+}
+
 // scan of one Aff per thread across the kPT-thread workgroup in sweep order (REV: descending
 // thread id): excl = composite of everything before this thread, total = the whole workgroup's
 template <bool REV>
@@ -1068,9 +1129,10 @@ __device__ inline double fold_incoming(SlotBuf rs, int slot_m, int slot_c, int n
     const int j = REV ? 63 - lane : lane;  // workgroup this lane polls
     Aff v{1.0, 0.0};
     if (j < nb) {
-        const d2 vm = ld_slot(rs, slot_m + j), vc = ld_slot(rs, slot_c + j);
-        v.m = poll_slot(rs, slot_m + j, vm, stamp, ok);
-        v.c = poll_slot(rs, slot_c + j, vc, stamp, ok);
+        d2 vm = ld_slot(rs, slot_m + j), vc = ld_slot(rs, slot_c + j);
+        poll_slots2(rs, slot_m + j, slot_c + j, true, vm, vc, stamp, ok);
+        v.m = vm.x;
+        v.c = vc.x;
     }
     // sweep order ascending in lanes: for the backward sweep lane j takes workgroup 63 - j
     // (lanes of absent workgroups hold the identity, wherever they sit)
@@ -1125,12 +1187,22 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     const int n = a.n;
     const int i0 = (b * kPT + tid) * E;
     Scalars* sc = a.sc;
+    // nothing to do (or nothing sane to do): an earlier solve of this asynchronous sequence
+    // failed, the Frank-Wolfe loop has stopped, or the preconditioner has a pivot <= 0
+    if (sc->err || sc->fw_done || sc->factor_bad) {
+        if (b == 0 && tid == 0 && sc->factor_bad && !sc->err) {
+            sc->done = 5;
+            sc->err = 5;
+        }
+        return;
+    }
     const SlotBuf xb = slot_buffer(a.xs, kSlotW + 2 * a.wstride);
+    const double stamp0 = a.ps->stamp_next;
     const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
     const double tol = sc->tol;
     const int max_iters = sc->max_iters;
     double theta = sc->theta;
-    int iters = sc->iters;
+    int iters = 0;
     int done = 0;
     int ok = 1;
     double res = 0.0;
@@ -1141,10 +1213,8 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         const int i = i0 + e;
         const bool in = i < n;
         x[e] = in ? a.x[i] : 0.0;
-        p[e] = in ? a.p[i] : 0.0;
-        Ax[e] = in ? a.Ax[i] : 0.0;
-        Ap[e] = in ? a.Ap[i] : 0.0;
-        r[e] = in ? a.r[i] : 0.0;
+        p[e] = 0.0;
+        Ap[e] = 0.0;
         lprev[e] = (in && i > 0) ? a.l[i - 1] : 0.0;
         lcur[e] = (in && i + 1 < n) ? a.l[i] : 0.0;
         idv[e] = in ? a.invd[i] : 0.0;
@@ -1152,64 +1222,93 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     // nodes past n carry zeros everywhere: their sweep elements are {0, 0}, harmless in both
     // directions (they come last in the forward sweep; node n-1 ignores its successor)
 
-    // composites of the first forward sweep + ||r||_1 of the bootstrap → iteration 0's inputs
-    Aff excl_f, tot;
+    // ---- bootstrap: Ax = L x from memory (x is the previous solve's vector or the cold start,
+    // written before this launch), 1x1 Rayleigh-Ritz (w = p = 0): theta = x'Ax / x'x, x
+    // normalised, r = Ax - theta x.  One exchange round (stamp0, parity 0) for the two sums.
     {
+        double g2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = i0 + e;
+            Ax[e] = i < n ? laplacian_row(i, n, a.rows, a.x, x[e]) : 0.0;
+            g2[0] += x[e] * x[e];
+            g2[1] += x[e] * Ax[e];
+        }
+        const double bs = block_sum_p<2>(g2, sred);
+        if (tid < 2) st_slot(xb, kSlotPt + (tid ? 6 : 0) * kPMaxBlocks + b, bs, stamp0);
+        if (wave < 2) {
+            const double v = fold_sum(xb, kSlotPt + (wave ? 6 : 0) * kPMaxBlocks, nb, stamp0, ok);
+            if (lane == 0) s_g[wave ? 6 : 0] = v;
+        }
+        if (!__syncthreads_and(ok)) done = 4;
+    }
+    Aff excl_f{1.0, 0.0}, tot;
+    if (!done) {
+        double g[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) g[q] = 0.0;
+        g[0] = s_g[0];
+        g[6] = s_g[6];
+        double coef[3];
+        if (!rr_step(g, coef, theta)) done = 2;
         Aff t{1.0, 0.0};
         double rs[1] = {0.0};
 #pragma unroll
         for (int e = 0; e < E; ++e) {
+            x[e] *= coef[0];
+            Ax[e] *= coef[0];
+            r[e] = Ax[e] - theta * x[e];
             t = compose(t, Aff{-lprev[e], r[e]});
             rs[0] += fabs(r[e]);
         }
+        // composites of the first forward sweep + ||r||_1 → iteration 0's inputs
         block_scan_p<false>(t, swave, excl_f, tot);
         const double bs = block_sum_p<1>(rs, sred);
-        if (tid == 0) {
-            st_slot(xb, kSlotXfM + b, tot.m, a.stamp0);
-            st_slot(xb, kSlotXfC + b, tot.c, a.stamp0);
-            st_slot(xb, kSlotRp + b, bs, a.stamp0);
+        if (tid == 0 && !done) {
+            st_slot(xb, kSlotXfM + kPMaxBlocks + b, tot.m, stamp0 + 1.0);
+            st_slot(xb, kSlotXfC + kPMaxBlocks + b, tot.c, stamp0 + 1.0);
+            st_slot(xb, kSlotRp + kPMaxBlocks + b, bs, stamp0 + 1.0);
         }
     }
-    // the first kPRowRegs active adjacency entries of every row stay in registers for the
-    // whole solve (a pose-graph row is two chain links + the odd loop closure).  Where an
-    // entry's neighbour is i-1 / i+1 and lives in this thread or the adjacent lane, its w comes
-    // from registers (kLeft / kRight); only the rest is gathered from the published slots
-    // (kRemote), and only nodes somebody gathers are published (pub[] from k_diag + the first /
-    // last node of every wave).
-    enum { kNone = 0, kRemote = 1, kLeft = 2, kRight = 3 };
-    int e0[E], cn[E], nbr[E][kPRowRegs], kind[E][kPRowRegs];
-    double rw[E][kPRowRegs];
+    // Row i of L(w) = chain terms (weights in registers; w of i-1 / i+1 comes from this thread's
+    // own registers or the adjacent lane, and only across a wave boundary from a published
+    // slot) + loop-closure entries gathered from published slots: the first kPRowRegs of a row
+    // have index and weight in registers for the whole solve, the rest is re-read from the
+    // (cached, read-only) adjacency.  Published: the targets of loop closures (pub[] from
+    // k_diag) and the first / last node of every wave.
+    double cl[E], cr[E], rw[E][kPRowRegs];
+    int e0[E], cn[E], nbr[E][kPRowRegs];
     bool publish[E];
-    bool any_remote = false;
+    bool any_remote = false, any_tail = false;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = i0 + e;
-        e0[e] = i < n ? a.adj_ptr[i] : 0;
-        cn[e] = i < n ? a.cnt[i] : 0;
-        publish[e] = i < n && (a.pub[i] != 0 || (e == 0 && lane == 0) || (e == E - 1 && lane == 63));
+        const bool in = i < n;
+        e0[e] = in ? a.rows.adj_ptr[i] : 0;
+        cn[e] = in ? a.rows.cnt[i] : 0;
+        cl[e] = in ? a.rows.chl[i] : 0.0;
+        cr[e] = in ? a.rows.chr[i] : 0.0;
+        publish[e] = in && (a.pub[i] != 0 || (e == 0 && lane == 0) || (e == E - 1 && lane == 63));
 #pragma unroll
         for (int q = 0; q < kPRowRegs; ++q) {
             const bool has = q < cn[e];
-            nbr[e][q] = has ? a.cnbr[e0[e] + q] : 0;
-            rw[e][q] = has ? a.caw[e0[e] + q] : 0.0;
-            int kd = kNone;
-            if (has) {
-                kd = kRemote;
-                if (nbr[e][q] == i - 1 && !(e == 0 && lane == 0)) kd = kLeft;
-                if (nbr[e][q] == i + 1 && !(e == E - 1 && lane == 63)) kd = kRight;
-            }
-            kind[e][q] = kd;
-            any_remote |= kd == kRemote;
+            nbr[e][q] = has ? a.rows.cnbr[e0[e] + q] : 0;
+            rw[e][q] = has ? a.rows.caw[e0[e] + q] : 0.0;
         }
-        any_remote |= cn[e] > kPRowRegs;
+        any_remote |= cn[e] > 0;
+        any_tail |= cn[e] > kPRowRegs;
     }
+    // chain neighbours across the wave boundary (lane 0's left, lane 63's right)
+    const bool edge_l = lane == 0 && cl[0] != 0.0;
+    const bool edge_r = lane == 63 && cr[E - 1] != 0.0;
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long plast = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const long long pstart = plast;
 
-    for (int k = 0;; ++k) {
-        const double stamp = a.stamp0 + (double)k;
-        const int par = k & 1;
+    int k = 0;
+    for (; !done; ++k) {
+        const double stamp = stamp0 + 1.0 + (double)k;
+        const int par = (k + 1) & 1;
         const int xo = par * kPMaxBlocks;
 
         // ---- A: residual norm + forward carries of every workgroup (published by D / above)
@@ -1227,13 +1326,13 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         PTICK(0);
         // convergence test of the last Ritz update (networkx criterion, see k_rr_solve)
         res = s_res / lnorm;
-        iters += 1;
         if (res < tol)
             done = 1;
         else if (iters >= max_iters)
             done = 3;
         if (!(res == res)) done = 2;
         if (done) break;
+        iters += 1;
 
         // forward apply, backward composites
         double y[E];
@@ -1286,38 +1385,122 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         // ---- C: Aw = L w (gathering the neighbours' w), Gram partials of S = [x, w - mu, p]
         double Aw[E];
         {
-            // remote entries first: all their slot loads in flight together
-            d2 gv[E][kPRowRegs];
+            // all slot loads of this thread in flight together: loop closures held in
+            // registers, the wave-boundary chain neighbours, the next kPRowTail entries of long
+            // rows (several loop closures on one pose: late Frank-Wolfe iterations)
+            d2 gv[E][kPRowRegs], gt[E][kPRowTail], gl{0.0, stamp}, gr{0.0, stamp};
+            int tn[E][kPRowTail];
             if (any_remote) {
 #pragma unroll
                 for (int e = 0; e < E; ++e)
 #pragma unroll
                     for (int q = 0; q < kPRowRegs; ++q)
-                        if (kind[e][q] == kRemote) gv[e][q] = ld_slot(xb, wslot + nbr[e][q]);
+                        if (q < cn[e]) gv[e][q] = ld_slot(xb, wslot + nbr[e][q]);
+            }
+            if (edge_l) gl = ld_slot(xb, wslot + i0 - 1);
+            if (edge_r) gr = ld_slot(xb, wslot + i0 + E);
+            if (any_tail) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int t = 0; t < kPRowTail; ++t)
+                        if (kPRowRegs + t < cn[e]) {
+                            tn[e][t] = a.rows.cnbr[e0[e] + kPRowRegs + t];
+                            gt[e][t] = ld_slot(xb, wslot + tn[e][t]);
+                        }
             }
             if (wave == 0) {
                 const double v = fold_sum(xb, kSlotPs + xo, nb, stamp, ok);
                 if (lane == 0) s_mu = v / (double)n;
             }
+            // wait until every gathered slot carries this iteration's stamp; the stale ones are
+            // re-read TOGETHER (one round trip per retry, not one per slot)
+            if (any_remote || edge_l || edge_r) {
+                long spins = 0;
+                while (true) {
+                    bool stale = (edge_l && gl.y != stamp) || (edge_r && gr.y != stamp);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+#pragma unroll
+                        for (int q = 0; q < kPRowRegs; ++q) stale |= q < cn[e] && gv[e][q].y != stamp;
+#pragma unroll
+                        for (int t = 0; t < kPRowTail; ++t)
+                            stale |= kPRowRegs + t < cn[e] && gt[e][t].y != stamp;
+                    }
+                    if (!stale) break;
+                    if (++spins > kSpinCap) {
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (edge_l && gl.y != stamp) gl = ld_slot(xb, wslot + i0 - 1);
+                    if (edge_r && gr.y != stamp) gr = ld_slot(xb, wslot + i0 + E);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+#pragma unroll
+                        for (int q = 0; q < kPRowRegs; ++q)
+                            if (q < cn[e] && gv[e][q].y != stamp)
+                                gv[e][q] = ld_slot(xb, wslot + nbr[e][q]);
+#pragma unroll
+                        for (int t = 0; t < kPRowTail; ++t)
+                            if (kPRowRegs + t < cn[e] && gt[e][t].y != stamp)
+                                gt[e][t] = ld_slot(xb, wslot + tn[e][t]);
+                    }
+                }
+            }
             // chain neighbours held by the adjacent lanes
-            const double w_before = dpp_mov<kDppWaveShr1>(w[E - 1], 0.0);
-            const double w_after = dpp_mov<kDppWaveShl1>(w[0], 0.0);
+            double w_before = dpp_mov<kDppWaveShr1>(w[E - 1], 0.0);
+            double w_after = dpp_mov<kDppWaveShl1>(w[0], 0.0);
+            if (edge_l) w_before = gl.x;
+            if (edge_r) w_after = gr.x;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double wl = e > 0 ? w[e > 0 ? e - 1 : 0] : w_before;
                 const double wr = e < E - 1 ? w[e < E - 1 ? e + 1 : 0] : w_after;
                 double acc = 0.0;
+                if (cl[e] != 0.0) acc += cl[e] * (w[e] - wl);
+                if (cr[e] != 0.0) acc += cr[e] * (w[e] - wr);
+                if (cn[e] > 0) {
 #pragma unroll
-                for (int q = 0; q < kPRowRegs; ++q) {
-                    const int kd = kind[e][q];
-                    double wn = kd == kLeft ? wl : wr;
-                    if (kd == kRemote) wn = poll_slot(xb, wslot + nbr[e][q], gv[e][q], stamp, ok);
-                    if (kd != kNone) acc += rw[e][q] * (w[e] - wn);
+                    for (int q = 0; q < kPRowRegs; ++q)
+                        if (q < cn[e]) acc += rw[e][q] * (w[e] - gv[e][q].x);
                 }
-                for (int q = kPRowRegs; q < cn[e]; ++q) {  // long rows: the rest, one by one
-                    const int sp = wslot + a.cnbr[e0[e] + q];
-                    const double wn = poll_slot(xb, sp, ld_slot(xb, sp), stamp, ok);
-                    acc += a.caw[e0[e] + q] * (w[e] - wn);
+                if (cn[e] > kPRowRegs) {
+#pragma unroll
+                    for (int t = 0; t < kPRowTail; ++t)
+                        if (kPRowRegs + t < cn[e])
+                            acc += a.rows.caw[e0[e] + kPRowRegs + t] * (w[e] - gt[e][t].x);
+                    // very long rows (a pose with more than kPRowRegs + kPRowTail loop closures):
+                    // the rest in batches of four, one round trip per batch
+                    for (int base = kPRowRegs + kPRowTail; base < cn[e]; base += 4) {
+                        d2 gx[4];
+                        int ix[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (base + t < cn[e]) {
+                                ix[t] = wslot + a.rows.cnbr[e0[e] + base + t];
+                                gx[t] = ld_slot(xb, ix[t]);
+                            }
+                        long spins = 0;
+                        while (true) {
+                            bool stale = false;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) stale |= base + t < cn[e] && gx[t].y != stamp;
+                            if (!stale) break;
+                            if (++spins > kSpinCap) {
+                                ok = 0;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (base + t < cn[e] && gx[t].y != stamp) gx[t] = ld_slot(xb, ix[t]);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (base + t < cn[e])
+                                acc += a.rows.caw[e0[e] + base + t] * (w[e] - gx[t].x);
+                    }
                 }
                 Aw[e] = acc;
             }
@@ -1368,8 +1551,9 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             }
             double g0 = 0.0, g1 = 0.0;
             if (lane < nb) {
-                g0 = poll_slot(xb, s0, v0, stamp, ok);
-                if (two) g1 = poll_slot(xb, s1, v1, stamp, ok);
+                poll_slots2(xb, s0, s1, two, v0, v1, stamp, ok);
+                g0 = v0.x;
+                if (two) g1 = v1.x;
             }
             g0 = wave_sum_dpp(g0);
             g1 = wave_sum_dpp(g1);
@@ -1430,14 +1614,24 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     if (b == 0 && tid == 0 && a.prof) {
         for (int q = 0; q < 8; ++q) a.prof[q] += pacc[q];
         a.prof[8] += (long long)__builtin_amdgcn_s_memtime() - pstart;
-        a.prof[9] += wall_clock64();  // unused
+    }
+    if (tid == 0 && a.prof) {
+        a.prof[16 + b] += pacc[4];       // per-workgroup gather time
+        a.prof[16 + 64 + b] += pacc[6];  // per-workgroup wait for the Gram sums
     }
     if (b == 0 && tid == 0) {
         sc->theta = theta;
         sc->res = res;
         sc->lnorm = lnorm;
         sc->iters = iters;
+        sc->total_iters += iters;
+        // a (numerically) zero Fiedler value means the graph is disconnected
+        if (done == 1 && !(theta > 1e-13 * lnorm)) done = 6;
         sc->done = done;
+        if (done != 1) sc->err = done;
+        // every workgroup read stamp_next before its first exchange, and this one cannot be
+        // here before all of them took part in that round
+        a.ps->stamp_next = stamp0 + (double)k + 4.0;
     }
 }
 
@@ -1481,8 +1675,8 @@ __device__ inline unsigned long long d2ord(double x) {
 
 // mask of the k largest entries of x[0..m): radix select (8 x 8 bits) in one 1024-thread block;
 // among entries equal to the k-th value the lowest indices are kept.
-__global__ __launch_bounds__(1024) void k_topk_mask(const double* __restrict__ x, int64_t m,
-                                                    int64_t k, double* __restrict__ mask) {
+__device__ inline void topk_mask_block(const double* __restrict__ x, int64_t m, int64_t k,
+                                       double* __restrict__ mask) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ long long s_krem;
@@ -1565,6 +1759,21 @@ struct TopkState {
     unsigned int list_count;
     int overflow;               // threshold bin larger than kTopkListCap → caller falls back
 };
+
+// single-block exact top-k (any number of ties)
+__global__ __launch_bounds__(1024) void k_topk_mask(const double* __restrict__ x, int64_t m,
+                                                    int64_t k, double* __restrict__ mask) {
+    topk_mask_block(x, m, k, mask);
+}
+// the same, but only when the multi-block path below gave up (massive exact ties): lets a
+// stream of launches stay asynchronous instead of asking the host
+__global__ __launch_bounds__(1024) void k_topk_mask_if_overflow(const double* __restrict__ x,
+                                                                int64_t m, int64_t k,
+                                                                double* __restrict__ mask,
+                                                                const TopkState* __restrict__ stt) {
+    if (!stt->overflow) return;
+    topk_mask_block(x, m, k, mask);
+}
 
 template <int LEVEL>
 __global__ __launch_bounds__(256) void k_topk_hist(const double* __restrict__ x, int64_t m,
@@ -1688,31 +1897,43 @@ __global__ __launch_bounds__(1024) void k_topk_finish(TopkState* __restrict__ st
 }
 
 // u = min(u, f + g.(s - w)); gap test (mac.py:219-225)
-__global__ __launch_bounds__(1024) void k_fw_dual(const double* __restrict__ g,
-                                                  const double* __restrict__ s,
-                                                  const double* __restrict__ w, int64_t m,
-                                                  Scalars* sc) {
-    __shared__ double smem[16];
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < m; i += 1024) acc += g[i] * (s[i] - w[i]);
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += smem[q];
-        double f = sc->theta;
-        double u = fmin(sc->fw_u, f + t);
-        sc->fw_f = f;
-        sc->fw_u = u;
-        sc->fw_done = (u - f < sc->fw_gap_tol) ? 1 : 0;
-    }
+// duality gap g . (s - w) in two deterministic stages: per-block partials, then one block
+__global__ __launch_bounds__(256) void k_fw_dual_part(const double* __restrict__ g,
+                                                      const double* __restrict__ s,
+                                                      const double* __restrict__ w, int64_t m,
+                                                      double* __restrict__ part) {
+    __shared__ double smem[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v[1] = {i < m ? g[i] * (s[i] - w[i]) : 0.0};
+    block_sum<1>(v, smem);
+    if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+// f = lambda_2(w), u = min(u, f + gap); stop flag; step size of this iteration (mac.py:213-230)
+__global__ __launch_bounds__(256) void k_fw_dual_final(const double* __restrict__ part, int npart,
+                                                       double* __restrict__ trace, int trace_cap,
+                                                       Scalars* sc) {
+    if (sc->fw_done || sc->err) return;
+    __shared__ double smem[4];
+    double v[1] = {0.0};
+    for (int b = threadIdx.x; b < npart; b += 256) v[0] += part[b];
+    block_sum<1>(v, smem);
+    if (threadIdx.x != 0) return;
+    const double f = sc->theta;
+    const double u = fmin(sc->fw_u, f + v[0]);
+    const int it = sc->fw_it;
+    sc->fw_f = f;
+    sc->fw_u = u;
+    if (trace && it < trace_cap) trace[it] = f;
+    sc->fw_alpha = 2.0 / ((double)it + 2.0);
+    sc->fw_it = it + 1;
+    sc->fw_done = (u - f < sc->fw_gap_tol) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fw_step(double* __restrict__ w,
                                                  const double* __restrict__ s, int64_t m,
                                                  const Scalars* sc) {
-    if (sc->fw_done) return;
+    if (sc->fw_done || sc->err) return;
     int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= m) return;
     double wk = w[k];
@@ -1736,6 +1957,7 @@ struct cslam_mac {
     int32_t *adj_ptr = nullptr, *adj_nbr = nullptr, *adj_eid = nullptr;
     int32_t *cnbr = nullptr, *cnt = nullptr;  // active adjacency of the current L(w) (k_diag)
     uint8_t* pub = nullptr;                   // nodes whose w some other thread gathers
+    double *chl = nullptr, *chr = nullptr;    // chain weights of the current L(w) (k_diag)
     int32_t *ci_d = nullptr, *cj_d = nullptr;
     double *cw_d = nullptr, *ew = nullptr, *aw = nullptr;
     int64_t nslot = 0;
@@ -1750,7 +1972,10 @@ struct cslam_mac {
     Scalars* sc = nullptr;
     d2* xslots = nullptr;      // stamped exchange slots of the persistent solver (PArgs)
     int64_t wstride = 0;
-    double stamp_next = 1.0;   // slots start zeroed; stamps only ever grow
+    PersistState* pstate = nullptr;  // device: next stamp (slots start zeroed; stamps only grow)
+    double* trace_d = nullptr;       // lambda_2 per Frank-Wolfe iteration (asynchronous loop)
+    int trace_cap = 0;
+    double* dual_part = nullptr;     // per-block partials of the duality-gap dot product
     long long* prof = nullptr;
     int persist_elems = 0;    // nodes per thread of the persistent solver (0 = graph path)
     int persist_blocks = 0;
@@ -1828,6 +2053,10 @@ void launch_topk(const double* x, int64_t m, int64_t k, double* mask, TopkState*
     hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, st, stt, mask, lkey, lidx);
 }
 
+RowsL rows_of(const cslam_mac* mac) {
+    return RowsL{mac->adj_ptr, mac->cnt, mac->cnbr, mac->aw, mac->chl, mac->chr};
+}
+
 void launch_iteration(cslam_mac* mac, hipStream_t st) {
     const int n = mac->n;
     const unsigned gs = (unsigned)mac->nscan;
@@ -1839,8 +2068,7 @@ void launch_iteration(cslam_mac* mac, hipStream_t st) {
     hipLaunchKernelGGL(k_bwd_apply, dim3(gs), dim3(kScanThreads), 0, st, mac->y, mac->l, mac->invd,
                        n, mac->agg_b, mac->w, mac->psum, mac->sc);
     // Aw = L w + the 12 Gram dot products
-    hipLaunchKernelGGL(k_spmv_dots, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->cnt, mac->cnbr,
-                       mac->aw, mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan,
+    hipLaunchKernelGGL(k_spmv_dots, dim3(gn), dim3(256), 0, st, rows_of(mac), mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan,
                        mac->partial, mac->sc);
     // convergence test of the previous update + 3x3 Rayleigh-Ritz
     hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, (int)gn, mac->psum,
@@ -1865,113 +2093,142 @@ int build_graph(cslam_mac* mac) {
 }
 
 // Fiedler pair of L(w) with w already on the device in mac->wvec.  Leaves theta in sc, v in x.
-int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
+// ---- one Fiedler solve = setup (edge weights, active adjacency, LDL^T) + iteration ------------
+// Everything is enqueued on mac->stream without touching the host, so that the Frank-Wolfe loop
+// can queue its iterations back to back; only the callers below synchronise.
+
+// Converge tighter than the reference's tol (networkx stops at res < tol = 1e-8 with an
+// eigenvector error of ~1e-6): the Ritz value error is O(res^2), the vector error O(res).
+inline double solver_tol(double tol_abi) { return tol_abi * 1e-2; }
+
+void enqueue_setup(cslam_mac* mac, double tol_abi) {
     const int n = mac->n;
     hipStream_t st = mac->stream;
     const unsigned gn = (unsigned)((n + 255) / 256);
-    if (mac->m > 0) {
-        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((mac->m + 255) / 256)), dim3(256), 0, st,
-                           mac->wvec, mac->cw_d, mac->m, 1e-10, mac->ew + mac->nf);
-    }
-    Scalars init;
-    std::memset(&init, 0, sizeof(init));
-    // Converge tighter than the reference's tol (networkx stops at res < tol = 1e-8 with an
-    // eigenvector error of ~1e-6): the Ritz value error is O(res^2), the vector error O(res).
-    init.tol = tol_abi * 1e-2;
-    init.max_iters = kMaxIters;
-    Scalars keep;
-    CSLAM_HIP_TRY(hipMemcpyAsync(&keep, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-    CSLAM_HIP_TRY(hipStreamSynchronize(st));
-    init.fw_f = keep.fw_f;
-    init.fw_u = keep.fw_u;
-    init.fw_gap_tol = keep.fw_gap_tol;
-    init.fw_alpha = keep.fw_alpha;
-    CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &init, sizeof(Scalars), hipMemcpyHostToDevice, st));
-    CSLAM_HIP_TRY(hipMemsetAsync(mac->pub, 0, (size_t)n, st));
+    const unsigned gp = (unsigned)std::min<int64_t>(std::max<int64_t>((mac->m + 255) / 256, gn), 4096);
+    hipLaunchKernelGGL(k_prepare, dim3(gp), dim3(256), 0, st, mac->wvec, mac->cw_d, mac->m, 1e-10,
+                       mac->ew + mac->nf, mac->pub, n, solver_tol(tol_abi), kMaxIters, mac->sc);
     hipLaunchKernelGGL(k_diag, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->adj_nbr, mac->adj_eid,
-                       mac->ew, mac->link, n, mac->a, mac->b, mac->cnbr, mac->aw, mac->cnt, mac->pub,
-                       kPRowRegs, mac->sc);
+                       mac->ew, mac->link, n, mac->a, mac->b, mac->cnbr, mac->aw, mac->cnt, mac->chl,
+                       mac->chr, mac->pub, mac->sc);
     hipLaunchKernelGGL(k_fact_agg, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
                        mac->b, n, mac->agg_m);
     hipLaunchKernelGGL(k_fact_apply, dim3((unsigned)mac->nfact), dim3(kScanThreads), 0, st, mac->a,
                        mac->b, n, mac->agg_m, mac->l, mac->invd, mac->sc);
+}
+
+// the whole bootstrap + iteration loop in one launch (k_lobpcg_persistent)
+void enqueue_persistent(cslam_mac* mac) {
+    PArgs pa{};
+    pa.rows = rows_of(mac);
+    pa.pub = mac->pub;
+    pa.l = mac->l;
+    pa.invd = mac->invd;
+    pa.x = mac->x;
+    pa.xs = mac->xslots;
+    pa.wstride = mac->wstride;
+    pa.ps = mac->pstate;
+    pa.sc = mac->sc;
+    pa.n = mac->n;
+    pa.prof = mac->prof;
+    const dim3 grid((unsigned)mac->persist_blocks), block(kPT);
+    hipStream_t st = mac->stream;
+    switch (mac->persist_elems) {
+        case 1: hipLaunchKernelGGL((k_lobpcg_persistent<1>), grid, block, 0, st, pa); break;
+        case 2: hipLaunchKernelGGL((k_lobpcg_persistent<2>), grid, block, 0, st, pa); break;
+        case 4: hipLaunchKernelGGL((k_lobpcg_persistent<4>), grid, block, 0, st, pa); break;
+        default: hipLaunchKernelGGL((k_lobpcg_persistent<8>), grid, block, 0, st, pa); break;
+    }
+}
+
+int read_scalars(cslam_mac* mac, Scalars& h) {
+    CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, mac->stream));
+    CSLAM_HIP_TRY(hipStreamSynchronize(mac->stream));
+    return CSLAM_OK;
+}
+
+// iterate with ordinary launches (graphs too large for the persistent grid, or its fallback):
+// bootstrap kernels, then hipGraph replays of 16 iterations polled by the host
+int solve_with_graph(cslam_mac* mac, Scalars& h) {
+    const int n = mac->n;
+    hipStream_t st = mac->stream;
+    const unsigned gn = (unsigned)((n + 255) / 256);
     // bootstrap: Ax = L x, 1x1 Rayleigh-Ritz (w = p = 0), r = Ax - theta x
-    auto bootstrap = [&]() -> int {
-        CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
-        CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
-        CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
-        CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
-        hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, mac->adj_ptr, mac->cnt, mac->cnbr,
-                           mac->aw, mac->x, mac->Ax, n, mac->sc);
-        hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w,
-                           mac->p, mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0,
-                           mac->partial, mac->sc);
-        hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
-                           mac->nscan, 0, n, (const double*)nullptr, 0, mac->sc);
-        hipLaunchKernelGGL(k_update_fwd_agg, dim3((unsigned)mac->nscan), dim3(kScanThreads), 0, st,
-                           mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n,
-                           mac->rpart, mac->agg_f, mac->sc);
-        hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nscan,
-                           mac->sc);
-        CSLAM_HIP_TRY(hipGetLastError());
-        return CSLAM_OK;
-    };
-    Scalars h;
-    auto poll = [&]() -> int {
-        CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-        CSLAM_HIP_TRY(hipStreamSynchronize(st));
-        if (h.factor_bad)
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->w, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->p, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->Aw, 0, sizeof(double) * n, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->Ap, 0, sizeof(double) * n, st));
+    hipLaunchKernelGGL(k_spmv, dim3(gn), dim3(256), 0, st, rows_of(mac), mac->x, mac->Ax, n, mac->sc);
+    hipLaunchKernelGGL(k_dots, dim3((unsigned)mac->nred), dim3(256), 0, st, mac->x, mac->w, mac->p,
+                       mac->Ax, mac->Aw, mac->Ap, n, mac->psum, mac->nscan, 0, mac->partial, mac->sc);
+    hipLaunchKernelGGL(k_rr_solve, dim3(1), dim3(256), 0, st, mac->partial, mac->nred, mac->psum,
+                       mac->nscan, 0, n, (const double*)nullptr, 0, mac->sc);
+    hipLaunchKernelGGL(k_update_fwd_agg, dim3((unsigned)mac->nscan), dim3(kScanThreads), 0, st,
+                       mac->x, mac->w, mac->p, mac->Ax, mac->Aw, mac->Ap, mac->r, mac->l, n,
+                       mac->rpart, mac->agg_f, mac->sc);
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(256), 0, st, mac->rpart, mac->nscan, mac->sc);
+    CSLAM_HIP_TRY(hipGetLastError());
+    CSLAM_TRY(read_scalars(mac, h));
+    if (!h.done && !h.factor_bad) CSLAM_TRY(build_graph(mac));
+    while (!h.done && !h.factor_bad) {
+        CSLAM_HIP_TRY(hipGraphLaunch(mac->graph, st));
+        CSLAM_TRY(read_scalars(mac, h));
+    }
+    if (h.done == 1 && !(h.theta > 1e-13 * h.lnorm)) h.done = 6;
+    if (h.factor_bad) h.done = 5;
+    return CSLAM_OK;
+}
+
+// `done` code of a finished solve → C-ABI status
+int solve_status(const Scalars& h) {
+    switch (h.done) {
+        case 1: return CSLAM_OK;
+        case 2: return fail(CSLAM_E_NOCONV, "LOBPCG breakdown (NaN / vanished basis)");
+        case 3:
+            return fail(CSLAM_E_NOCONV, "LOBPCG did not reach res < %.3g in %d iterations (res %.3g)",
+                        h.tol, h.iters, h.res);
+        case 5:
             return fail(CSLAM_E_DISCONNECTED,
                         "tridiagonal pivot <= 0: L(w) has an isolated node (disconnected graph)");
-        return CSLAM_OK;
-    };
-    CSLAM_TRY(bootstrap());
-    CSLAM_TRY(poll());
-    if (!h.done && mac->persist_elems > 0) {
-        // the whole iteration loop in one launch (k_lobpcg_persistent)
-        PArgs pa{};
-        pa.adj_ptr = mac->adj_ptr; pa.cnt = mac->cnt; pa.cnbr = mac->cnbr; pa.caw = mac->aw; pa.pub = mac->pub;
-        pa.l = mac->l; pa.invd = mac->invd;
-        pa.x = mac->x; pa.p = mac->p; pa.Ax = mac->Ax; pa.Ap = mac->Ap; pa.r = mac->r;
-        pa.xs = mac->xslots;
-        pa.wstride = mac->wstride;
-        pa.stamp0 = mac->stamp_next;
-        pa.sc = mac->sc; pa.n = n; pa.prof = mac->prof;
-        mac->stamp_next += (double)(kMaxIters + 4);
-        const dim3 grid((unsigned)mac->persist_blocks), block(kPT);
-        switch (mac->persist_elems) {
-            case 1: hipLaunchKernelGGL((k_lobpcg_persistent<1>), grid, block, 0, st, pa); break;
-            case 2: hipLaunchKernelGGL((k_lobpcg_persistent<2>), grid, block, 0, st, pa); break;
-            case 4: hipLaunchKernelGGL((k_lobpcg_persistent<4>), grid, block, 0, st, pa); break;
-            default: hipLaunchKernelGGL((k_lobpcg_persistent<8>), grid, block, 0, st, pa); break;
-        }
+        case 6: return fail(CSLAM_E_DISCONNECTED, "lambda_2 = %.3g ~ 0: disconnected graph", h.theta);
+        default: return fail(CSLAM_E_HIP, "Fiedler solver ended in state %d", h.done);
+    }
+}
+
+int clear_sticky_error(cslam_mac* mac) {
+    const int zero = 0;
+    CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->err, &zero, sizeof(int), hipMemcpyHostToDevice, mac->stream));
+    return CSLAM_OK;
+}
+
+// Fiedler pair of L(w) with w already on the device in mac->wvec.  Leaves theta in sc, v in x.
+int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
+    Scalars h;
+    CSLAM_TRY(clear_sticky_error(mac));
+    enqueue_setup(mac, tol_abi);
+    bool solved = false;
+    if (mac->persist_elems > 0) {
+        enqueue_persistent(mac);
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_TRY(poll());
+        CSLAM_TRY(read_scalars(mac, h));
         if (h.done == 4) {
-            // a barrier was not met in time (the CUs were held by someone else's kernel):
-            // x is untouched, redo the bootstrap and iterate with ordinary launches
+            // an exchange round was not met in time (the CUs were held by someone else's
+            // kernel): x is untouched, iterate with ordinary launches instead
             mac->persist_fallbacks += 1;
-            const int zero = 0;
-            CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->done, &zero, sizeof(int), hipMemcpyHostToDevice, st));
-            CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->iters, &zero, sizeof(int), hipMemcpyHostToDevice, st));
-            CSLAM_TRY(bootstrap());
-            CSLAM_TRY(poll());
+            CSLAM_TRY(clear_sticky_error(mac));
+        } else {
+            solved = true;
         }
     }
-    if (!h.done) CSLAM_TRY(build_graph(mac));
-    while (!h.done) {
-        CSLAM_HIP_TRY(hipGraphLaunch(mac->graph, st));
-        CSLAM_TRY(poll());
+    if (!solved) {
+        CSLAM_HIP_TRY(hipGetLastError());
+        CSLAM_TRY(solve_with_graph(mac, h));
+        mac->spmv_count += h.iters;
+    } else {
+        mac->spmv_count += h.iters;
     }
-    mac->spmv_count += h.iters;
     if (iters_out) *iters_out = h.iters;
-    if (h.done == 2) return fail(CSLAM_E_NOCONV, "LOBPCG breakdown (NaN / vanished basis)");
-    if (h.done == 3)
-        return fail(CSLAM_E_NOCONV, "LOBPCG did not reach res < %.3g in %d iterations (res %.3g)",
-                    init.tol, h.iters, h.res);
-    // a (numerically) zero Fiedler value means the graph is disconnected
-    if (!(h.theta > 1e-13 * h.lnorm))
-        return fail(CSLAM_E_DISCONNECTED, "lambda_2 = %.3g ~ 0: disconnected graph", h.theta);
+    CSLAM_TRY(solve_status(h));
     mac->have_warm = true;
     return CSLAM_OK;
 }
@@ -2124,6 +2381,8 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->cnbr, nbr.size()));
     A(dev_alloc(&mac->cnt, n));
     A(dev_alloc(&mac->pub, n));
+    A(dev_alloc(&mac->chl, n));
+    A(dev_alloc(&mac->chr, n));
     A(dev_alloc(&mac->link, n));
     for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
                        &mac->Aw, &mac->Ap, &mac->r, &mac->y})
@@ -2135,14 +2394,16 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     A(dev_alloc(&mac->partial, (size_t)npartial * 12));
     A(dev_alloc(&mac->rpart, std::max(mac->nred, mac->nscan)));
     A(dev_alloc(&mac->sc, 1));
+    A(dev_alloc(&mac->pstate, 1));
+    A(dev_alloc(&mac->dual_part, (size_t)((n_cand + 255) / 256)));
     mac->wstride = ((int64_t)n + 63) / 64 * 64;
     const size_t nslots = (size_t)(kSlotW + 2 * mac->wstride);
     A(dev_alloc(&mac->xslots, nslots));
     if (mac->xslots && hipMemset(mac->xslots, 0, nslots * sizeof(d2)) != hipSuccess)
         A(fail(CSLAM_E_HIP, "mac_create: memset failed"));
     if (getenv("CSLAM_MAC_PROF")) {
-        A(dev_alloc(&mac->prof, 16));
-        if (mac->prof) (void)hipMemset(mac->prof, 0, 16 * sizeof(long long));
+        A(dev_alloc(&mac->prof, 16 + 128));
+        if (mac->prof) (void)hipMemset(mac->prof, 0, (16 + 128) * sizeof(long long));
     }
     A(dev_alloc(&mac->wvec, n_cand));
     A(dev_alloc(&mac->gvec, n_cand));
@@ -2170,6 +2431,8 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     std::vector<double> x0;
     cold_start_vector(n, x0);
     H2D(mac->x, x0.data(), (size_t)n * 8);
+    const PersistState ps0{1.0};
+    H2D(mac->pstate, &ps0, sizeof(ps0));
     if (rc == CSLAM_OK && (hipMemset(mac->sc, 0, sizeof(Scalars)) != hipSuccess ||
                            hipMemset(mac->l, 0, sizeof(double) * n) != hipSuccess ||
                            hipMemset(mac->tk_hist, 0, sizeof(unsigned int) * kTopkBins) != hipSuccess ||
@@ -2197,16 +2460,26 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
             for (int k = 0; k < 9; ++k)
                 fprintf(stderr, " %s %.1f", nm[k], h[k] / (double)std::max<int64_t>(1, mac->spmv_count));
             fprintf(stderr, "\n");
+            long long pb[128];
+            if (hipMemcpy(pb, mac->prof + 16, sizeof(pb), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[cslam mac prof] per-workgroup gatherC / pollD ticks per iter:");
+                for (int b = 0; b < mac->persist_blocks && b < 64; ++b)
+                    fprintf(stderr, " %d:%.0f/%.0f", b, pb[b] / (double)std::max<int64_t>(1, mac->spmv_count),
+                            pb[64 + b] / (double)std::max<int64_t>(1, mac->spmv_count));
+                fprintf(stderr, "\n");
+            }
         }
     }
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
     for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
-                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->cnbr, (void*)mac->cnt, (void*)mac->pub, (void*)mac->link,
+                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->cnbr, (void*)mac->cnt, (void*)mac->pub, (void*)mac->chl, (void*)mac->chr,
+                    (void*)mac->link,
                     (void*)mac->a, (void*)mac->b,
                     (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
                     (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
                     (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->agg_m, (void*)mac->psum, (void*)mac->partial,
-                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->xslots, (void*)mac->prof, (void*)mac->wvec, (void*)mac->gvec,
+                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->pstate, (void*)mac->dual_part,
+                    (void*)mac->trace_d, (void*)mac->xslots, (void*)mac->prof, (void*)mac->wvec, (void*)mac->gvec,
                     (void*)mac->svec, (void*)mac->tk_state, (void*)mac->tk_hist, (void*)mac->tk_lkey,
                     (void*)mac->tk_lidx})
         if (p) (void)hipFree(p);
@@ -2391,72 +2664,121 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
     hipStream_t st = mac->stream;
     const int64_t m = mac->m;
     const unsigned gm = (unsigned)((m + 255) / 256);
-    std::vector<double> hw(w_init, w_init + m);
+    if (max_iters > mac->trace_cap) {
+        if (mac->trace_d) (void)hipFree(mac->trace_d);
+        mac->trace_d = nullptr;
+        mac->trace_cap = 0;
+        CSLAM_TRY(dev_alloc(&mac->trace_d, (size_t)max_iters));
+        mac->trace_cap = max_iters;
+    }
     Scalars h;
     std::memset(&h, 0, sizeof(h));
     h.fw_u = INFINITY;
     h.fw_gap_tol = duality_gap_tol;
     CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &h, sizeof(Scalars), hipMemcpyHostToDevice, st));
-    CSLAM_HIP_TRY(hipMemcpyAsync(mac->wvec, hw.data(), m * 8, hipMemcpyHostToDevice, st));
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->wvec, w_init, m * 8, hipMemcpyHostToDevice, st));
     CSLAM_HIP_TRY(hipEventRecord(mac->ev0, st));
-    int it = 0;
-    double u = INFINITY;
-    bool stopped = false;
-    for (; it < max_iters; ++it) {
-        if (!mac->fixed_connected) {
-            // rare path (fixed graph alone is not connected): the support of w decides
-            CSLAM_HIP_TRY(hipMemcpyAsync(hw.data(), mac->wvec, m * 8, hipMemcpyDeviceToHost, st));
-            CSLAM_HIP_TRY(hipStreamSynchronize(st));
-            if (!graph_connected(mac, hw.data(), 1e-10))
-                return fail(CSLAM_E_DISCONNECTED, "fw_subset: L(w) disconnected at iteration %d", it);
-        }
-        // keep the FW scalars across the solver's reset
-        const double alpha = 2.0 / (it + 2.0);
-        CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->fw_alpha, &alpha, 8, hipMemcpyHostToDevice, st));
-        int32_t its = 0;
-        int rc = fiedler_device(mac, 1e-8, &its);
-        if (rc != CSLAM_OK) {
-            std::vector<double> x0;
-            cold_start_vector(mac->n, x0);
-            (void)hipMemcpy(mac->x, x0.data(), (size_t)mac->n * 8, hipMemcpyHostToDevice);
-            mac->have_warm = false;
-            return rc;
-        }
+
+    // gradient of lambda_2, its k largest entries, duality gap, step — all on the device
+    auto enqueue_fw_tail = [&]() {
         hipLaunchKernelGGL(k_grad, dim3(gm), dim3(256), 0, st, mac->ci_d, mac->cj_d, mac->cw_d,
                            mac->x, m, mac->gvec);
         launch_topk(mac->gvec, m, k, mac->svec, mac->tk_state, mac->tk_hist, mac->tk_lkey,
                     mac->tk_lidx, st);
-        {
-            TopkState ts;
-            CSLAM_HIP_TRY(hipMemcpyAsync(&ts, mac->tk_state, sizeof(ts), hipMemcpyDeviceToHost, st));
-            CSLAM_HIP_TRY(hipStreamSynchronize(st));
-            if (k > 0 && k < m && ts.overflow)  // > 4096 entries tie with the k-th value
-                hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, st, mac->gvec, m, k,
-                                   mac->svec);
-        }
-        hipLaunchKernelGGL(k_fw_dual, dim3(1), dim3(1024), 0, st, mac->gvec, mac->svec, mac->wvec, m,
-                           mac->sc);
+        if (k > 0 && k < m)  // > 4096 entries tie with the k-th value: exact single-block path
+            hipLaunchKernelGGL(k_topk_mask_if_overflow, dim3(1), dim3(1024), 0, st, mac->gvec, m, k,
+                               mac->svec, mac->tk_state);
+        hipLaunchKernelGGL(k_fw_dual_part, dim3(gm), dim3(256), 0, st, mac->gvec, mac->svec,
+                           mac->wvec, m, mac->dual_part);
+        hipLaunchKernelGGL(k_fw_dual_final, dim3(1), dim3(256), 0, st, mac->dual_part, (int)gm,
+                           mac->trace_d, mac->trace_cap, mac->sc);
         hipLaunchKernelGGL(k_fw_step, dim3(gm), dim3(256), 0, st, mac->wvec, mac->svec, m, mac->sc);
+    };
+    auto reset_start_vector = [&]() {
+        std::vector<double> x0;
+        cold_start_vector(mac->n, x0);
+        (void)hipMemcpy(mac->x, x0.data(), (size_t)mac->n * 8, hipMemcpyHostToDevice);
+        mac->have_warm = false;
+    };
+
+    bool need_sync_loop = !(mac->persist_elems > 0 && mac->fixed_connected);
+    if (!need_sync_loop) {
+        // The whole Frank-Wolfe loop is queued without a single host round trip: every kernel
+        // of an iteration that comes after the stop flag (duality gap reached) or after a failed
+        // solve returns at once, and the host reads the outcome when the queue has drained.
+        for (int it = 0; it < max_iters; ++it) {
+            enqueue_setup(mac, 1e-8);
+            enqueue_persistent(mac);
+            enqueue_fw_tail();
+        }
         CSLAM_HIP_TRY(hipGetLastError());
-        CSLAM_HIP_TRY(hipMemcpyAsync(&h, mac->sc, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-        CSLAM_HIP_TRY(hipStreamSynchronize(st));
-        if (lambda_trace) lambda_trace[it] = h.fw_f;
-        u = h.fw_u;
-        if (h.fw_done) {  // "Duality gap tolerance reached" (mac.py:223-225): w is NOT stepped
-            ++it;
-            stopped = true;
-            break;
+        CSLAM_HIP_TRY(hipEventRecord(mac->ev1, st));
+        CSLAM_TRY(read_scalars(mac, h));
+        mac->spmv_count += h.total_iters;
+        if (h.err == 4) {
+            // an exchange round of the persistent solver timed out: redo the selection with
+            // host-paced launches, from the caller's w and a fresh start vector
+            mac->persist_fallbacks += 1;
+            reset_start_vector();
+            std::memset(&h, 0, sizeof(h));
+            h.fw_u = INFINITY;
+            h.fw_gap_tol = duality_gap_tol;
+            CSLAM_HIP_TRY(hipMemcpyAsync(mac->sc, &h, sizeof(Scalars), hipMemcpyHostToDevice, st));
+            CSLAM_HIP_TRY(hipMemcpyAsync(mac->wvec, w_init, m * 8, hipMemcpyHostToDevice, st));
+            CSLAM_HIP_TRY(hipEventRecord(mac->ev0, st));
+            need_sync_loop = true;
+        } else if (h.err) {
+            h.done = h.err;
+            reset_start_vector();
+            return solve_status(h);
+        } else {
+            mac->have_warm = true;
         }
     }
-    (void)stopped;
-    CSLAM_HIP_TRY(hipEventRecord(mac->ev1, st));
+    if (need_sync_loop) {
+        // host-paced loop: graphs too large for the persistent grid, and fixed graphs that are
+        // not connected by themselves (the support of w decides, checked on the host)
+        std::vector<double> hw(m);
+        const int saved_persist = mac->persist_elems;
+        if (h.err == 0 && saved_persist > 0 && mac->fixed_connected) mac->persist_elems = 0;
+        for (int it = 0; it < max_iters; ++it) {
+            if (!mac->fixed_connected) {
+                CSLAM_HIP_TRY(hipMemcpyAsync(hw.data(), mac->wvec, m * 8, hipMemcpyDeviceToHost, st));
+                CSLAM_HIP_TRY(hipStreamSynchronize(st));
+                if (!graph_connected(mac, hw.data(), 1e-10)) {
+                    mac->persist_elems = saved_persist;
+                    return fail(CSLAM_E_DISCONNECTED, "fw_subset: L(w) disconnected at iteration %d",
+                                it);
+                }
+            }
+            int32_t its = 0;
+            const int rc = fiedler_device(mac, 1e-8, &its);
+            if (rc != CSLAM_OK) {
+                mac->persist_elems = saved_persist;
+                reset_start_vector();
+                return rc;
+            }
+            enqueue_fw_tail();
+            CSLAM_HIP_TRY(hipGetLastError());
+            CSLAM_TRY(read_scalars(mac, h));
+            if (h.fw_done) break;  // "Duality gap tolerance reached" (mac.py:223-225)
+        }
+        mac->persist_elems = saved_persist;
+        CSLAM_HIP_TRY(hipEventRecord(mac->ev1, st));
+    }
+    // h: the final scalars.  fw_it iterations were evaluated (the one that met the duality-gap
+    // tolerance included, mac.py:223-225: its w is NOT stepped)
+    const int it_done = h.fw_it;
+    if (lambda_trace && it_done > 0)
+        CSLAM_HIP_TRY(hipMemcpyAsync(lambda_trace, mac->trace_d, sizeof(double) * it_done,
+                                     hipMemcpyDeviceToHost, st));
     CSLAM_HIP_TRY(hipMemcpyAsync(w_relaxed, mac->wvec, m * 8, hipMemcpyDeviceToHost, st));
     CSLAM_HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     CSLAM_HIP_TRY(hipEventElapsedTime(&ms, mac->ev0, mac->ev1));
     mac->device_ms = ms;
-    *upper = u;
-    if (iters_done) *iters_done = it;
+    *upper = h.fw_u;
+    if (iters_done) *iters_done = it_done;
     return cslam_mac_round_tiebreak(mac, w_relaxed, k, 10, w_round);
 }
 

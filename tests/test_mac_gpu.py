@@ -290,3 +290,42 @@ def test_cfg3_fiedler_matches_scipy_eigsh(gpu):
     r = L @ v - lam * v
     assert np.abs(r).sum() / (2 * L.diagonal().max()) < 1e-9
     mac.close()
+
+
+@pytest.mark.parametrize("n,hubs,hub_degree", [(3000, 3, 5), (5000, 2, 9), (6000, 2, 80), (2100, 1, 150)])
+def test_fiedler_with_hub_poses_matches_dense_eigh(gpu, n, hubs, hub_degree):
+    """Poses with many active loop closures (rows of L(w) longer than the persistent solver keeps
+    in registers, up to more than a wave's worth), three odometry chains, candidate edges between
+    index neighbours, zero-weight candidates: lambda_2 and v_2 against numpy's dense eigh."""
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    rs = np.random.RandomState(n + hub_degree)
+    third = n // 3
+    fixed = [Edge(i, i + 1, 1.0 + 0.25 * rs.rand()) for i in range(n - 1)
+             if (i + 1) % third != 0 or i + 1 >= 3 * third]
+    fixed += [Edge(third - 1, 2 * third + 5, 0.7), Edge(third + 3, 3 * third - 2, 1.3)]
+    cand = []
+    for h in range(hubs):
+        hub = int(rs.randint(n))
+        others = rs.choice(np.setdiff1d(np.arange(n), [hub - 1, hub, hub + 1]), hub_degree, replace=False)
+        cand += [Edge(hub, int(o), float(0.2 + rs.rand())) for o in others]
+    cand += [Edge(int(i), int(i) + 1, 0.5) for i in rs.choice(n - 1, 20, replace=False)]   # index neighbours
+    cand += [Edge(int(a), int(b), float(rs.rand())) for a, b in rs.randint(n, size=(400, 2)) if a != b]
+    w = np.ones(len(cand))
+    w[rs.choice(len(cand), len(cand) // 3, replace=False)] = 0.0     # inactive candidates
+    w[: hubs * hub_degree] = 0.3 + 0.7 * rs.rand(hubs * hub_degree)  # every hub edge active
+    mac = MAC(fixed, cand, n)
+    lam, v = mac.evaluate_fiedler_pair(w)
+    L = mac.combined_laplacian(w).toarray()
+    ev, evec = np.linalg.eigh(L)
+    assert ev[1] > 1e-9, "test graph must be connected"
+    assert abs(lam - ev[1]) < 1e-10 + 1e-7 * ev[1]
+    ref = mo.sign_normalise(evec[:, 1])
+    assert np.abs(mo.sign_normalise(v) - ref).max() < 1e-5 * max(1.0, ev[1] / (ev[2] - ev[1]))
+    r = L @ v - lam * v
+    assert np.abs(r).sum() / (2 * L.diagonal().max()) < 1e-9
+    # a second solve from the warm vector with other weights, then back: same answer
+    lam2, _ = mac.evaluate_fiedler_pair(np.minimum(1.0, w + 0.1))
+    lam3, v3 = mac.evaluate_fiedler_pair(w)
+    assert lam2 >= lam - 1e-12 and abs(lam3 - lam) < 1e-12 + 1e-9 * lam
+    mac.close()
