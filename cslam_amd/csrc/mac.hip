@@ -642,7 +642,11 @@ __device__ inline bool rqi_smallest(const double (&C)[3][3], double& theta, doub
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < K; ++i) t += v[i] * cv[i];
+        // cubic convergence from a nearly diagonal C: two steps are the rule; a Rayleigh
+        // quotient that no longer moves ends the iteration (the certificate below still decides)
+        const bool settled = fabs(t - th) <= 4e-16 * scale;
         th = t;
+        if (settled) break;
     }
     double cv[3];
     sym_matvec<K>(C, v, cv);
