@@ -33,6 +33,15 @@ __global__ __launch_bounds__(256) void k(const float* X, size_t n_rows, size_t n
                     acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][2], v[u][2], acc3, 0, 0, 0);
                     acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][3], v[u][3], acc4, 0, 0, 0);
                 }
+                if (MODE == 4) {  // accumulator in AccVGPRs
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %1, %0" : "+a"(acc) : "v"(v[u][j]));
+                }
+                if (MODE == 5) {  // 4x4x1 (16 blocks), 8 cycles each, same flops per loaded value? (2 passes)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(v[u][j], v[u][j], acc, 0, 0, 0);
+                }
                 if (MODE == 3) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[u][j], v[u][j], acc[j]);
@@ -58,6 +67,8 @@ int main() {
     hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, X, N * D); hipDeviceSynchronize();
     size_t bytes = N * D * 4;
 #define RUN(MODE, U, WPC, label) timeit(label " U=" #U " wpc=" #WPC, [&] { size_t nw = 256 * WPC; hipLaunchKernelGGL((k<MODE, U>), dim3(nw / 4), dim3(256), 0, 0, X, N, nw, out); }, bytes)
+    RUN(4, 8, 16, "mfma acc in AGPR"); RUN(4, 8, 8, "mfma acc in AGPR"); RUN(4, 8, 4, "mfma acc in AGPR");
+    RUN(5, 8, 16, "mfma 4x4x1 (1/4 the MFMA time)"); RUN(5, 8, 8, "mfma 4x4x1 (1/4 the MFMA time)"); RUN(5, 8, 4, "mfma 4x4x1 (1/4 the MFMA time)");
     RUN(0, 8, 16, "add"); RUN(1, 8, 16, "mfma dependent chain"); RUN(2, 8, 16, "mfma 4 independent"); RUN(3, 8, 16, "valu fma");
     RUN(0, 8, 8, "add"); RUN(1, 8, 8, "mfma dependent chain"); RUN(2, 8, 8, "mfma 4 independent"); RUN(3, 8, 8, "valu fma");
     RUN(0, 8, 4, "add"); RUN(1, 8, 4, "mfma dependent chain"); RUN(2, 8, 4, "mfma 4 independent");
