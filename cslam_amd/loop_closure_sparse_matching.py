@@ -59,6 +59,31 @@ class LoopClosureSparseMatching(object):
                 matches.append(match)
         return matches
 
+    def add_local_global_descriptors_device(self, embeddings, keyframe_ids):
+        """Batched, device-resident form of add_local_global_descriptor: `embeddings` is a CUDA
+        float32 tensor [B, D] straight from the VPR head (cslam_amd.vpr), appended to the local
+        pool device-to-device and matched against every other robot's pool with one scan per
+        pool.  Equivalent to the singular method called in order (the other robots' pools do not
+        change meanwhile); only the B (keyframe, similarity) results per pool reach the host.
+
+        Returns: list(EdgeInterRobot) — the candidates created, in keyframe order per robot."""
+        keyframe_ids = [int(k) for k in keyframe_ids]
+        self.local_nnsm.add_items_tensor(embeddings, keyframe_ids)
+        me = self.params["robot_id"]
+        matches = []
+        per_robot = {}
+        for i in range(self.params["max_nb_robots"]):
+            if i != me:
+                per_robot[i] = self.other_robots_nnsm[i].search_best_batch_tensor(embeddings)
+        for row, keyframe_id in enumerate(keyframe_ids):     # the reference's nesting order
+            for i, (kfs, sims) in per_robot.items():
+                kf, similarity = kfs[row], sims[row]
+                if kf is not None and similarity >= self.params["frontend.similarity_threshold"]:
+                    match = EdgeInterRobot(me, keyframe_id, i, kf, similarity)
+                    self.candidate_selector.add_match(match)
+                    matches.append(match)
+        return matches
+
     # ---- lcsm.py:58-76 ---------------------------------------------------------------------
     def add_other_robot_global_descriptor(self, msg):
         """Add a keyframe descriptor received from another robot and match it against the

@@ -170,6 +170,44 @@ class NearestNeighborsMatching(object):
             self.items[self.n] = it
             self.n += 1
 
+    def add_items_tensor(self, vectors, items):
+        """Append the rows of a CUDA float32 tensor [B, dim] (e.g. descriptors straight out of the
+        VPR head): device-to-device, on torch's current stream, no host round trip."""
+        import torch
+        if not (isinstance(vectors, torch.Tensor) and vectors.is_cuda):
+            raise TypeError("add_items_tensor expects a CUDA tensor (use add_items for host data)")
+        if vectors.dim() != 2 or vectors.dtype != torch.float32 or vectors.stride(1) != 1:
+            raise ValueError("add_items_tensor expects float32 [B, dim] with unit inner stride")
+        if len(items) != vectors.shape[0]:
+            raise ValueError("add_items_tensor: len(items) != number of rows")
+        if vectors.shape[0] == 0:
+            return
+        if self._pool is None:
+            self._create(vectors.shape[1])
+        if vectors.shape[1] != self.dim:
+            raise ValueError(f"descriptor size {vectors.shape[1]} != pool dim {self.dim}")
+        self.add_items_device(vectors.data_ptr(), vectors.shape[0], vectors.stride(0), list(items),
+                              stream=torch.cuda.current_stream().cuda_stream)
+
+    def search_best_batch_tensor(self, queries):
+        """search_best_batch for queries that live in HBM (CUDA float32 [M, dim]): only the M
+        (row, similarity) pairs come back to the host."""
+        import torch
+        m = queries.shape[0]
+        if self._pool is None or self.n == 0:
+            return [None] * m, [None] * m
+        if queries.dim() != 2 or queries.dtype != torch.float32 or queries.stride(1) != 1 \
+                or queries.shape[1] != self.dim:
+            raise ValueError("search_best_batch_tensor expects float32 [M, dim] with unit inner stride")
+        idx = torch.empty((m, 1), dtype=torch.int32, device=queries.device)
+        sim = torch.empty((m, 1), dtype=torch.float32, device=queries.device)
+        _lib.check(self._lib.cslam_pool_search_dev(
+            self._pool, ctypes.c_void_p(queries.data_ptr()), queries.stride(0), m, 1,
+            ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        rows = idx[:, 0].cpu().numpy()
+        return [self.items[int(r)] for r in rows], sim[:, 0].cpu().numpy()
+
     # -- search (nns_matching.py:44-63) --------------------------------------------------
     def search_batch(self, queries, k):
         """Top-k of every query row in one pass.

@@ -446,6 +446,68 @@ def gen_broker():
     print("broker_ref.json:", {k: [len(c) for c in v["covers"]] for k, v in cases.items()})
 
 
+def gen_vpr():
+    """Aggregation heads of the two VPR front ends, run through the reference's
+    own layer classes on CPU: cslam/vpr/cosplace_utils/layers.py (imported by path: it only needs
+    torch) and NetVLADLayer of cslam/vpr/netvlad.py (module imports torchvision / PIL / sklearn at
+    the top, none of which the layer uses: stubbed for the import when absent)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_cosplace_layers",
+                                                  os.path.join(REF, "cslam/vpr/cosplace_utils/layers.py"))
+    layers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(layers)
+    for name in ("torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models", "PIL",
+                 "PIL.Image"):
+        try:
+            __import__(name)
+        except ImportError:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["torchvision"], "transforms"):
+        sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+        sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+        sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    if not hasattr(sys.modules["PIL"], "Image"):
+        sys.modules["PIL"].Image = sys.modules["PIL.Image"]
+    from cslam.vpr.netvlad import NetVLADLayer
+
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    # CosPlace head: L2Norm -> GeM -> Flatten -> Linear -> L2Norm (network.py:33-39)
+    feats = torch.randn(3, 96, 7, 5, generator=g) * torch.rand(3, 96, 1, 1, generator=g) * 3.0
+    fc = torch.nn.Linear(96, 40)
+    with torch.no_grad():
+        fc.weight.copy_(torch.randn(40, 96, generator=g) * 0.2)
+        fc.bias.copy_(torch.randn(40, generator=g) * 0.1)
+    gem = layers.GeM()
+    with torch.no_grad():
+        gem.p.fill_(2.7)
+    head = torch.nn.Sequential(layers.L2Norm(), gem, layers.Flatten(), fc, layers.L2Norm()).eval()
+    with torch.no_grad():
+        out["cos_feats"] = feats.numpy()
+        out["cos_fc_w"] = fc.weight.numpy().copy()
+        out["cos_fc_b"] = fc.bias.numpy().copy()
+        out["cos_p"] = np.float32(2.7)
+        out["cos_gem"] = torch.nn.Sequential(layers.L2Norm(), gem, layers.Flatten())(feats).numpy()
+        out["cos_out"] = head(feats).numpy()
+    # NetVLAD layer, both variants
+    for tag, v2 in (("v1", False), ("v2", True)):
+        layer = NetVLADLayer(num_clusters=6, dim=24, vladv2=v2).eval()
+        with torch.no_grad():
+            layer.conv.weight.copy_(torch.randn(6, 24, 1, 1, generator=g))
+            if v2:
+                layer.conv.bias.copy_(torch.randn(6, generator=g) * 0.3)
+            layer.centroids.copy_(torch.rand(6, 24, generator=g))
+            x = torch.randn(2, 24, 5, 4, generator=g)
+            out[f"vlad_{tag}_x"] = x.numpy()
+            out[f"vlad_{tag}_conv_w"] = layer.conv.weight.numpy().copy()
+            if v2:
+                out[f"vlad_{tag}_conv_b"] = layer.conv.bias.numpy().copy()
+            out[f"vlad_{tag}_centroids"] = layer.centroids.numpy().copy()
+            out[f"vlad_{tag}_out"] = layer(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "vpr_ref.npz"), **out)
+    print("vpr_ref.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
 if __name__ == "__main__":
     random.seed(0)
     np.random.seed(0)
@@ -455,3 +517,4 @@ if __name__ == "__main__":
     gen_lcsm()
     gen_broker()
     gen_cfg1()
+    gen_vpr()
