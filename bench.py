@@ -59,11 +59,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal knobs (one-GPU boxes): CSLAM_BENCH_BACKEND=gloo exchanges through host memory,
+    # CSLAM_BENCH_SAME_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
+    backend = os.environ.get("CSLAM_BENCH_BACKEND", "nccl")
+    if os.environ.get("CSLAM_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     L = _lib.load()
     N, D = args.keyframes, args.dim
