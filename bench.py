@@ -225,6 +225,13 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    # MAC first: the solver is latency-bound, and the clocks sag for a while after the
+    # 100-TFLOP/s bulk pass below
+    try:
+        from cslam_amd.mac.bench_util import fiedler_bench
+        out.update(fiedler_bench())
+    except ImportError:
+        pass
     q1 = torch.rand((1, D), device=dev, generator=g)
     q16 = torch.rand((16, D), device=dev, generator=g)
     q1024 = torch.rand((1024, D), device=dev, generator=g)
@@ -236,11 +243,6 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     out["bulk_1024queries_ms"] = t * 1e3
     out["bulk_1024queries_candidates_per_s"] = 1024 / t
     out["bulk_1024queries_tflops"] = 2.0 * N * D * 1024 / t / 1e12
-    try:
-        from cslam_amd.mac.bench_util import fiedler_bench
-        out.update(fiedler_bench())
-    except ImportError:
-        pass
     return out
 
 

@@ -18,7 +18,7 @@
 // preconditioner M = tridiag(L(w)) restricted to the fixed odometry chains (SPD because L is
 // diagonally dominant; parameter-free).  M is factored LDL^T once per solve; M z = r is two
 // first-order linear recurrences = two parallel affine scans.  ~270 iterations cold at cfg3
-// scale, ~80 warm (vs ~3e5 SpMVs for Jacobi-PCG TraceMIN).  Converged to a
+// scale, ~70 warm (vs ~3e5 SpMVs for Jacobi-PCG TraceMIN).  Converged to a 10x
 // TIGHTER residual than the reference's tol so the eigenvector (hence the gradient ranking) is
 // at least as accurate.
 //
@@ -1030,7 +1030,7 @@ constexpr int kPWaves = kPT / 64;
 constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
 constexpr int kPMaxElems = 8;
 constexpr int kPRowRegs = 3;     // adjacency entries of a row kept in registers
-constexpr int kPRowTail = 2;     // further entries whose loads join the first batch
+constexpr int kPOverflow = 2;    // overflow-table entries a thread serves for its workgroup
 constexpr long kSpinCap = 1L << 20;
 
 typedef double d2 __attribute__((ext_vector_type(2)));  // {value, stamp}
@@ -1186,6 +1186,8 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     __shared__ Aff swave[kPWaves];
     __shared__ double sred[12 * kPWaves];
     __shared__ double s_vin, s_res, s_vinb, s_mu, s_g[12];
+    __shared__ int s_ovw[kPWaves], s_ov_pos[kPOverflow * kPT], s_ov_own[kPOverflow * kPT];
+    __shared__ double s_w[kPT * E], s_term[kPOverflow * kPT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = gridDim.x, b = blockIdx.x;
     const int n = a.n;
@@ -1277,13 +1279,14 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     // Row i of L(w) = chain terms (weights in registers; w of i-1 / i+1 comes from this thread's
     // own registers or the adjacent lane, and only across a wave boundary from a published
     // slot) + loop-closure entries gathered from published slots: the first kPRowRegs of a row
-    // have index and weight in registers for the whole solve, the rest is re-read from the
-    // (cached, read-only) adjacency.  Published: the targets of loop closures (pub[] from
-    // k_diag) and the first / last node of every wave.
+    // have index and weight in the registers of the row's thread for the whole solve, the rest
+    // goes to the workgroup's overflow table (below).  Published: the targets of loop closures
+    // (pub[] from k_diag) and the first / last node of every wave.
     double cl[E], cr[E], rw[E][kPRowRegs];
     int e0[E], cn[E], nbr[E][kPRowRegs];
     bool publish[E];
-    bool any_remote = false, any_tail = false;
+    bool any_remote = false;
+    int oc = 0;  // this thread's loop-closure entries beyond the registers
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = i0 + e;
@@ -1300,7 +1303,63 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             rw[e][q] = has ? a.rows.caw[e0[e] + q] : 0.0;
         }
         any_remote |= cn[e] > 0;
-        any_tail |= cn[e] > kPRowRegs;
+        oc += max(cn[e] - kPRowRegs, 0);
+    }
+    // Overflow table: the entries that do not fit the registers of their row's thread (hub
+    // poses with many loop closures) are dealt out over ALL threads of the workgroup, up to
+    // kPOverflow each, so that every slot load of an iteration is issued in the same batch
+    // whatever the row lengths.  A serving thread keeps (neighbour, weight, owner) in registers;
+    // per iteration the owners' w goes through LDS to the servers and the products come back.
+    int ov_off, ov_total;
+    {
+        int incl = oc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_ovw[wave] = incl;
+        __syncthreads();
+        int pre = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < kPWaves; ++q) {
+            if (q < wave) pre += s_ovw[q];
+            tot += s_ovw[q];
+        }
+        ov_off = pre + incl - oc;
+        ov_total = tot;
+    }
+    constexpr int kOvCap = kPOverflow * kPT;
+    const int ov_mine = min(max(kOvCap - ov_off, 0), oc);  // how many of my entries are in the table
+    int h_nbr[kPOverflow], h_own[kPOverflow];
+    double h_w[kPOverflow];
+    bool h_on[kPOverflow];
+    if (ov_total > 0) {
+        int pos = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            for (int q = kPRowRegs; q < cn[e]; ++q, ++pos)
+                if (pos < ov_mine) {
+                    s_ov_pos[ov_off + pos] = e0[e] + q;
+                    s_ov_own[ov_off + pos] = tid * E + e;
+                }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPOverflow; ++j) {
+            const int k = tid + j * kPT;
+            h_on[j] = k < min(ov_total, kOvCap);
+            const int ap = h_on[j] ? s_ov_pos[k] : 0;
+            h_own[j] = h_on[j] ? s_ov_own[k] : 0;
+            h_nbr[j] = h_on[j] ? a.rows.cnbr[ap] : 0;
+            h_w[j] = h_on[j] ? a.rows.caw[ap] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPOverflow; ++j) {
+            h_on[j] = false;
+            h_nbr[j] = h_own[j] = 0;
+            h_w[j] = 0.0;
+        }
     }
     // chain neighbours across the wave boundary (lane 0's left, lane 63's right)
     const bool edge_l = lane == 0 && cl[0] != 0.0;
@@ -1390,10 +1449,8 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         double Aw[E];
         {
             // all slot loads of this thread in flight together: loop closures held in
-            // registers, the wave-boundary chain neighbours, the next kPRowTail entries of long
-            // rows (several loop closures on one pose: late Frank-Wolfe iterations)
-            d2 gv[E][kPRowRegs], gt[E][kPRowTail], gl{0.0, stamp}, gr{0.0, stamp};
-            int tn[E][kPRowTail];
+            // registers, the wave-boundary chain neighbours, the overflow entries it serves
+            d2 gv[E][kPRowRegs], gh[kPOverflow], gl{0.0, stamp}, gr{0.0, stamp};
             if (any_remote) {
 #pragma unroll
                 for (int e = 0; e < E; ++e)
@@ -1403,15 +1460,12 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             }
             if (edge_l) gl = ld_slot(xb, wslot + i0 - 1);
             if (edge_r) gr = ld_slot(xb, wslot + i0 + E);
-            if (any_tail) {
 #pragma unroll
-                for (int e = 0; e < E; ++e)
+            for (int j = 0; j < kPOverflow; ++j)
+                if (h_on[j]) gh[j] = ld_slot(xb, wslot + h_nbr[j]);
+            if (ov_total > 0) {
 #pragma unroll
-                    for (int t = 0; t < kPRowTail; ++t)
-                        if (kPRowRegs + t < cn[e]) {
-                            tn[e][t] = a.rows.cnbr[e0[e] + kPRowRegs + t];
-                            gt[e][t] = ld_slot(xb, wslot + tn[e][t]);
-                        }
+                for (int e = 0; e < E; ++e) s_w[tid * E + e] = w[e];
             }
             if (wave == 0) {
                 const double v = fold_sum(xb, kSlotPs + xo, nb, stamp, ok);
@@ -1419,18 +1473,16 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             }
             // wait until every gathered slot carries this iteration's stamp; the stale ones are
             // re-read TOGETHER (one round trip per retry, not one per slot)
-            if (any_remote || edge_l || edge_r) {
+            if (any_remote || edge_l || edge_r || h_on[0]) {
                 long spins = 0;
                 while (true) {
                     bool stale = (edge_l && gl.y != stamp) || (edge_r && gr.y != stamp);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
+                    for (int e = 0; e < E; ++e)
 #pragma unroll
                         for (int q = 0; q < kPRowRegs; ++q) stale |= q < cn[e] && gv[e][q].y != stamp;
 #pragma unroll
-                        for (int t = 0; t < kPRowTail; ++t)
-                            stale |= kPRowRegs + t < cn[e] && gt[e][t].y != stamp;
-                    }
+                    for (int j = 0; j < kPOverflow; ++j) stale |= h_on[j] && gh[j].y != stamp;
                     if (!stale) break;
                     if (++spins > kSpinCap) {
                         ok = 0;
@@ -1440,23 +1492,29 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                     if (edge_l && gl.y != stamp) gl = ld_slot(xb, wslot + i0 - 1);
                     if (edge_r && gr.y != stamp) gr = ld_slot(xb, wslot + i0 + E);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
+                    for (int e = 0; e < E; ++e)
 #pragma unroll
                         for (int q = 0; q < kPRowRegs; ++q)
                             if (q < cn[e] && gv[e][q].y != stamp)
                                 gv[e][q] = ld_slot(xb, wslot + nbr[e][q]);
 #pragma unroll
-                        for (int t = 0; t < kPRowTail; ++t)
-                            if (kPRowRegs + t < cn[e] && gt[e][t].y != stamp)
-                                gt[e][t] = ld_slot(xb, wslot + tn[e][t]);
-                    }
+                    for (int j = 0; j < kPOverflow; ++j)
+                        if (h_on[j] && gh[j].y != stamp) gh[j] = ld_slot(xb, wslot + h_nbr[j]);
                 }
+            }
+            if (ov_total > 0) {  // uniform over the workgroup
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < kPOverflow; ++j)
+                    if (h_on[j]) s_term[tid + j * kPT] = h_w[j] * (s_w[h_own[j]] - gh[j].x);
+                __syncthreads();
             }
             // chain neighbours held by the adjacent lanes
             double w_before = dpp_mov<kDppWaveShr1>(w[E - 1], 0.0);
             double w_after = dpp_mov<kDppWaveShl1>(w[0], 0.0);
             if (edge_l) w_before = gl.x;
             if (edge_r) w_after = gr.x;
+            int opos = 0;  // position among this thread's overflow entries
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double wl = e > 0 ? w[e > 0 ? e - 1 : 0] : w_before;
@@ -1469,42 +1527,38 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                     for (int q = 0; q < kPRowRegs; ++q)
                         if (q < cn[e]) acc += rw[e][q] * (w[e] - gv[e][q].x);
                 }
-                if (cn[e] > kPRowRegs) {
+                int q = kPRowRegs;
+                for (; q < cn[e] && opos < ov_mine; ++q, ++opos) acc += s_term[ov_off + opos];
+                // a workgroup with more overflow than its table holds: the rest of the row in
+                // batches of four, one round trip per batch
+                for (int base = q; base < cn[e]; base += 4) {
+                    d2 gx[4];
+                    int ix[4];
 #pragma unroll
-                    for (int t = 0; t < kPRowTail; ++t)
-                        if (kPRowRegs + t < cn[e])
-                            acc += a.rows.caw[e0[e] + kPRowRegs + t] * (w[e] - gt[e][t].x);
-                    // very long rows (a pose with more than kPRowRegs + kPRowTail loop closures):
-                    // the rest in batches of four, one round trip per batch
-                    for (int base = kPRowRegs + kPRowTail; base < cn[e]; base += 4) {
-                        d2 gx[4];
-                        int ix[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (base + t < cn[e]) {
-                                ix[t] = wslot + a.rows.cnbr[e0[e] + base + t];
-                                gx[t] = ld_slot(xb, ix[t]);
-                            }
-                        long spins = 0;
-                        while (true) {
-                            bool stale = false;
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) stale |= base + t < cn[e] && gx[t].y != stamp;
-                            if (!stale) break;
-                            if (++spins > kSpinCap) {
-                                ok = 0;
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                if (base + t < cn[e] && gx[t].y != stamp) gx[t] = ld_slot(xb, ix[t]);
+                    for (int t = 0; t < 4; ++t)
+                        if (base + t < cn[e]) {
+                            ix[t] = wslot + a.rows.cnbr[e0[e] + base + t];
+                            gx[t] = ld_slot(xb, ix[t]);
                         }
+                    long spins = 0;
+                    while (true) {
+                        bool stale = false;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) stale |= base + t < cn[e] && gx[t].y != stamp;
+                        if (!stale) break;
+                        if (++spins > kSpinCap) {
+                            ok = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
-                            if (base + t < cn[e])
-                                acc += a.rows.caw[e0[e] + base + t] * (w[e] - gx[t].x);
+                            if (base + t < cn[e] && gx[t].y != stamp) gx[t] = ld_slot(xb, ix[t]);
                     }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (base + t < cn[e]) acc += a.rows.caw[e0[e] + base + t] * (w[e] - gx[t].x);
+                    opos += min(4, cn[e] - base);
                 }
                 Aw[e] = acc;
             }
@@ -2102,8 +2156,13 @@ int build_graph(cslam_mac* mac) {
 // can queue its iterations back to back; only the callers below synchronise.
 
 // Converge tighter than the reference's tol (networkx stops at res < tol = 1e-8 with an
-// eigenvector error of ~1e-6): the Ritz value error is O(res^2), the vector error O(res).
-inline double solver_tol(double tol_abi) { return tol_abi * 1e-2; }
+// eigenvector error of ~1e-6): the Ritz value error is O(res^2), the vector error O(res).  10x
+// tighter keeps every golden selection identical; 100x costs 15 % more iterations for nothing.
+inline double solver_tol(double tol_abi) {
+    static const double f =
+        getenv("CSLAM_MAC_TOL_FACTOR") ? atof(getenv("CSLAM_MAC_TOL_FACTOR")) : 1e-1;
+    return tol_abi * f;
+}
 
 void enqueue_setup(cslam_mac* mac, double tol_abi) {
     const int n = mac->n;

@@ -292,7 +292,8 @@ def test_cfg3_fiedler_matches_scipy_eigsh(gpu):
     mac.close()
 
 
-@pytest.mark.parametrize("n,hubs,hub_degree", [(3000, 3, 5), (5000, 2, 9), (6000, 2, 80), (2100, 1, 150)])
+@pytest.mark.parametrize("n,hubs,hub_degree", [(3000, 3, 5), (5000, 2, 9), (6000, 2, 80), (2100, 1, 150),
+                                               (1000, 9, 140)])  # last: more overflow than one table holds
 def test_fiedler_with_hub_poses_matches_dense_eigh(gpu, n, hubs, hub_degree):
     """Poses with many active loop closures (rows of L(w) longer than the persistent solver keeps
     in registers, up to more than a wave's worth), three odometry chains, candidate edges between
