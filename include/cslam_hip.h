@@ -146,6 +146,22 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
 /* Solver statistics of the last cslam_mac_fiedler / cslam_mac_fw_subset call. */
 int cslam_mac_stats(const cslam_mac_t* mac, int64_t* spmv_count, double* device_ms);
 
+/* ------------------------------------------------------------------------------------------
+ * Geometric verification stand-in.  The reference hands matched 3D keypoints
+ * to rtabmap's RegistrationVis (src/front_end/rgbd_handler.cpp:684-706); this is a functional
+ * replacement, parity unpinned by construction (third-party code outside the tree).
+ * RANSAC over `iterations` 3-correspondence samples of src[n][3] -> dst[n][3] (host pointers):
+ *   sample_transform[12]  rotation (row-major 3x3) then translation of the best sample
+ *   inlier_sums[16]       over its inliers: sum src (3), sum dst (3), sum src_i*dst_j (9), count
+ *                         — enough for the caller's least-squares (Kabsch) refinement
+ *   inlier_mask[n]        optional, 1 = inlier of the best sample
+ *   best_hypothesis       optional, index of the best sample (-1: none valid)
+ * Deterministic for a given seed: most inliers wins, ties go to the lowest sample index. */
+int cslam_ransac_rigid3d(const float* src, const float* dst, int64_t n, int iterations,
+                         double inlier_distance, uint64_t seed, int device_id,
+                         double* sample_transform, double* inlier_sums, uint8_t* inlier_mask,
+                         int32_t* best_hypothesis);
+
 #ifdef __cplusplus
 }
 #endif
