@@ -15,6 +15,15 @@ from .algebraic_connectivity_maximization import (AlgebraicConnectivityMaximizat
 from .nns_matching import NearestNeighborsMatching
 
 
+class _Descriptor(object):
+    """(robot_id, keyframe_id) of a descriptor that arrived without a ROS message."""
+    __slots__ = ("robot_id", "keyframe_id")
+
+    def __init__(self, robot_id, keyframe_id):
+        self.robot_id = robot_id
+        self.keyframe_id = keyframe_id
+
+
 class LoopClosureSparseMatching(object):
 
     def __init__(self, params, node, device_id=0):
@@ -120,6 +129,21 @@ class LoopClosureSparseMatching(object):
             self.other_robots_nnsm[rid].add_items(vectors[rows], [msgs[r].keyframe_id for r in rows])
         kfs, sims = self.local_nnsm.search_best_batch(vectors)
         return [self._candidate_from_best(m, kf, s) for m, kf, s in zip(msgs, kfs, sims)]
+
+    def add_other_robot_global_descriptors_device(self, robot_id, embeddings, keyframe_ids):
+        """Device-resident form of add_other_robot_global_descriptors for descriptors of ONE
+        other robot that already live in HBM (an all-gathered block, or a co-located robot's VPR
+        output): CUDA float32 [B, D] appended to that robot's pool and matched against the local
+        pool in one scan, only the B results reach the host.
+
+        Returns: list of (EdgeInterRobot or None), one per row."""
+        keyframe_ids = [int(k) for k in keyframe_ids]
+        self.other_robots_nnsm[robot_id].add_items_tensor(embeddings, keyframe_ids)
+        kfs, sims = self.local_nnsm.search_best_batch_tensor(embeddings)
+        out = []
+        for keyframe_id, kf, s in zip(keyframe_ids, kfs, sims):
+            out.append(self._candidate_from_best(_Descriptor(robot_id, keyframe_id), kf, s))
+        return out
 
     # ---- lcsm.py:78-97 ---------------------------------------------------------------------
     def match_local_loop_closures(self, descriptor, kf_id):
