@@ -330,3 +330,53 @@ def test_fiedler_with_hub_poses_matches_dense_eigh(gpu, n, hubs, hub_degree):
     lam3, v3 = mac.evaluate_fiedler_pair(w)
     assert lam2 >= lam - 1e-12 and abs(lam3 - lam) < 1e-12 + 1e-9 * lam
     mac.close()
+
+
+def test_persistent_solver_shares_the_gpu_with_concurrent_scans(gpu):
+    """The persistent Fiedler kernel needs all its workgroups resident to make progress; the
+    node runs kNN scans (their own streams, 1024 waves of the chip) at the same time.  Selection
+    results must not change and nothing may hang or fall back silently into an error."""
+    import threading
+    import time as _time
+    from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    n, fixed, cand = cfg3_graph(poses_per_robot=6000, nb_candidates=30_000, seed=3)
+    w0 = greedy_w(cand, 200)
+    mac = MAC(fixed, cand, n)
+    with redirect_stdout(io.StringIO()):
+        base_round, base_relaxed, base_upper = mac.fw_subset(w0, 200, max_iters=10)
+    mac.close()
+
+    rs = np.random.RandomState(0)
+    pool = NearestNeighborsMatching(dim=1024)
+    pool.add_items(rs.rand(60_000, 1024).astype(np.float32), list(range(60_000)))
+    queries = rs.rand(16, 1024).astype(np.float32)
+    stop = threading.Event()
+    scans = [0]
+    errors = []
+
+    def scan_forever():
+        try:
+            while not stop.is_set():
+                pool.search_best_batch(queries)
+                scans[0] += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=scan_forever)
+    th.start()
+    try:
+        _time.sleep(0.05)
+        for _ in range(3):
+            mac = MAC(fixed, cand, n)
+            with redirect_stdout(io.StringIO()):
+                rounded, relaxed, upper = mac.fw_subset(w0, 200, max_iters=10)
+            mac.close()
+            np.testing.assert_array_equal(rounded, base_round)
+            np.testing.assert_allclose(relaxed, base_relaxed, atol=1e-9)
+            assert abs(upper - base_upper) < 1e-9
+    finally:
+        stop.set()
+        th.join(timeout=60)
+    assert not errors and scans[0] > 10
