@@ -380,3 +380,31 @@ def test_persistent_solver_shares_the_gpu_with_concurrent_scans(gpu):
         stop.set()
         th.join(timeout=60)
     assert not errors and scans[0] > 10
+
+
+@pytest.mark.parametrize("case", CASES[:2])
+def test_graph_captured_solver_path_matches_reference(gpu, case, monkeypatch):
+    """The launch-per-phase solver (hipGraph of 16 iterations; graphs beyond the persistent
+    kernel's size, and its fallback) must give the same answers: forced with the creation-time
+    knob CSLAM_MAC_PERSISTENT=0."""
+    monkeypatch.setenv("CSLAM_MAC_PERSISTENT", "0")
+    mac, g = _mac(case)
+    lam, v = mac.evaluate_fiedler_pair(g("w_init"))
+    assert abs(lam - g("lambda_trace")[0]) < 1e-9
+    np.testing.assert_allclose(v, g("v0"), atol=2e-5)
+    k = int(g("nb")[3])
+    with redirect_stdout(io.StringIO()):
+        rounded, relaxed, upper = mac.fw_subset(g("w_init"), k, max_iters=20)
+    np.testing.assert_allclose(mac.lambda_trace, g("lambda_trace"), atol=1e-9)
+    np.testing.assert_array_equal(rounded, g("rounded"))
+    # a disconnected L(w) raises on this path too, and the handle recovers
+    from cslam_amd._lib import GraphDisconnectedError
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    m2 = MAC([Edge(0, 1, 1.0), Edge(2, 3, 1.0)], [Edge(1, 2, 1.0)], 4)
+    with pytest.raises(GraphDisconnectedError):
+        m2.evaluate_fiedler_pair(np.zeros(1))
+    lam2, _ = m2.evaluate_fiedler_pair(np.ones(1))
+    assert abs(lam2 - (2 - np.sqrt(2))) < 1e-9
+    m2.close()
+    mac.close()
