@@ -275,3 +275,71 @@ def _sequential_reference_with(blocks, world, steps):
         for k, e in sel[r].candidate_edges.items():
             union[k] = max(union.get(k, -1.0), float(e.weight))
     return union, [m.size for m in local]
+
+
+@pytest.mark.gpu
+def test_cfg4_full_size_protocol_properties(gpu):
+    """BASELINE.json configs[3] at its real size on ONE GPU: 8 robot shards (threads) x 25 000
+    keyframes x 4096-d resident, then protocol steps whose new descriptors are planted copies of
+    rows that live in OTHER shards.  Size-independent properties: every planted copy produces the
+    candidate (owner, row) with similarity 1, every replica of the candidate set is identical,
+    no candidate is produced for fresh random descriptors under a 0.95 threshold."""
+    import threading
+    from cslam_amd.multi_robot import HipPoolMatcher, ShardedLoopClosureMatching
+    world, rows, dim, steps, per_step = 8, 25_000, 4096, 3, 4
+    shared = ThreadComm.Shared(world)
+    results, errors, planted_all = [None] * world, [], {}
+    dev = torch.device("cuda", 0)
+    # what every rank plants at every step: (owner shard, owner row) — owner != rank
+    rs = np.random.RandomState(0)
+    plan = {(t, r): [((r + 1 + int(rs.randint(world - 1))) % world, int(rs.randint(rows)))
+                     for _ in range(per_step)] for t in range(steps) for r in range(world)}
+    pools = [None] * world
+
+    def base_rows(rank):
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        return torch.rand((rows, dim), device=dev, generator=g)
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            m = HipPoolMatcher(dim, capacity_hint=rows + steps * (per_step + 1))
+            x = base_rows(rank)
+            m.add_rows(x, list(range(rows)))
+            pools[rank] = x
+            sh = ShardedLoopClosureMatching(ThreadComm(shared, rank), m, 0.95, max_block=per_step + 1)
+            shared.barrier.wait()           # every shard's base rows exist before anybody plants
+            for t in range(steps):
+                copies = torch.stack([pools[s][j] for s, j in plan[(t, rank)]])
+                g = torch.Generator(device=dev).manual_seed(9000 + 10 * t + rank)
+                fresh = torch.rand((1, dim), device=dev, generator=g)
+                block = torch.cat([copies, fresh]).contiguous()
+                kfs = [rows + t * (per_step + 1) + i for i in range(per_step + 1)]
+                sh.step(block, kfs)
+            results[rank] = {k: float(v.weight) for k, v in sh.candidate_selector.candidate_edges.items()}
+        except Exception as e:  # surface worker failures in the main thread
+            errors.append(e)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    for r in range(1, world):
+        assert results[r] == results[0]                         # identical replicas
+    expected = set()
+    for (t, r), lst in plan.items():
+        for i, (s, j) in enumerate(lst):
+            kf_new = rows + t * (per_step + 1) + i
+            a, b = (s, j), (r, kf_new)
+            lo, hi = (a, b) if a[0] < b[0] else (b, a)
+            expected.add((lo[0], lo[1], hi[0], hi[1]))
+    got = set(results[0])
+    assert expected <= got, sorted(expected - got)[:5]
+    for k in expected:
+        assert abs(results[0][k] - 1.0) < 1e-6
+    # copies of the same base row planted by two ranks also match each other; nothing else may
+    # appear: every extra candidate must be between two planted keyframes
+    for k in got - expected:
+        assert k[1] >= rows and k[3] >= rows, k
