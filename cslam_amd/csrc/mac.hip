@@ -36,6 +36,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <vector>
 
@@ -2704,17 +2705,38 @@ int cslam_mac_round_tiebreak(cslam_mac_t* mac, const double* w, int64_t k, int d
     const double scale = std::pow(10.0, decimals);
     std::vector<double> tw(m);
     for (int64_t i = 0; i < m; ++i) tw[i] = std::nearbyint(w[i] * scale) / scale;  // np.round
-    std::vector<int64_t> order(m);
-    std::iota(order.begin(), order.end(), 0);
     const int64_t kk = std::min(k, m);
-    auto better = [&](int64_t a, int64_t b) {
-        if (tw[a] != tw[b]) return tw[a] > tw[b];
-        if (mac->cw[a] != mac->cw[b]) return mac->cw[a] > mac->cw[b];
-        return a < b;
-    };
-    if (kk > 0 && kk < m) std::nth_element(order.begin(), order.begin() + (kk - 1), order.end(), better);
     for (int64_t i = 0; i < m; ++i) mask[i] = 0.0;
-    for (int64_t i = 0; i < kk; ++i) mask[order[i]] = 1.0;
+    if (kk <= 0) return CSLAM_OK;
+    if (kk >= m) {
+        for (int64_t i = 0; i < m; ++i) mask[i] = 1.0;
+        return CSLAM_OK;
+    }
+    // kk-th largest rounded value by selection on the plain values; only the entries that tie
+    // with it need the (weight desc, index asc) order
+    std::vector<double> vals(tw);
+    std::nth_element(vals.begin(), vals.begin() + (kk - 1), vals.end(), std::greater<double>());
+    const double thr = vals[kk - 1];
+    int64_t above = 0;
+    std::vector<int64_t> ties;
+    for (int64_t i = 0; i < m; ++i) {
+        if (tw[i] > thr) {
+            mask[i] = 1.0;
+            ++above;
+        } else if (tw[i] == thr) {
+            ties.push_back(i);
+        }
+    }
+    const int64_t need = kk - above;
+    if (need > 0) {
+        auto better = [&](int64_t a, int64_t b) {
+            if (mac->cw[a] != mac->cw[b]) return mac->cw[a] > mac->cw[b];
+            return a < b;
+        };
+        if (need < (int64_t)ties.size())
+            std::nth_element(ties.begin(), ties.begin() + (need - 1), ties.end(), better);
+        for (int64_t i = 0; i < need && i < (int64_t)ties.size(); ++i) mask[ties[i]] = 1.0;
+    }
     return CSLAM_OK;
 }
 

@@ -145,6 +145,14 @@ class MAC:
         rounded = np.empty(m, np.float64)
         _lib.check(self._lib.cslam_mac_round_tiebreak(self._handle, _lib.ptr(w), int(k),
                                                       int(decimal_tol), _lib.ptr(rounded)))
+        return self._resolve_boundary_tie(w, rounded, k, decimal_tol)
+
+    def _resolve_boundary_tie(self, w, rounded, k, decimal_tol=10):
+        """`rounded` is the native selection (ties at the boundary → higher weight, then lower
+        index).  If the last selected and the first rejected key are EXACTLY equal the reference's
+        outcome is whatever numpy's introselect leaves in the last k slots: evaluate that very
+        call then; otherwise the set is unique and `rounded` stands."""
+        m = len(w)
         tw = w.round(decimals=decimal_tol)
         sel = rounded > 0.5
         lo_tw = tw[sel].min()
@@ -188,7 +196,9 @@ class MAC:
             print("Duality gap tolerance reached, found optimal solution")  # mac.py:224
         else:
             print("Reached maximum iterations")  # mac.py:232
-        return self.round_solution_tiebreaker(w_relaxed, k), w_relaxed, upper.value
+        if 0 < k < m:   # the library already rounded w_relaxed; only a boundary tie needs numpy
+            w_round = self._resolve_boundary_tie(w_relaxed, w_round, k)
+        return w_round, w_relaxed, upper.value
 
     def stats(self):
         """(solver iterations so far, device ms of the last fiedler / fw_subset call)."""
