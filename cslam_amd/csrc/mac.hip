@@ -1824,15 +1824,6 @@ __global__ __launch_bounds__(1024) void k_topk_mask(const double* __restrict__ x
                                                     int64_t k, double* __restrict__ mask) {
     topk_mask_block(x, m, k, mask);
 }
-// the same, but only when the multi-block path below gave up (massive exact ties): lets a
-// stream of launches stay asynchronous instead of asking the host
-__global__ __launch_bounds__(1024) void k_topk_mask_if_overflow(const double* __restrict__ x,
-                                                                int64_t m, int64_t k,
-                                                                double* __restrict__ mask,
-                                                                const TopkState* __restrict__ stt) {
-    if (!stt->overflow) return;
-    topk_mask_block(x, m, k, mask);
-}
 
 template <int LEVEL>
 __global__ __launch_bounds__(256) void k_topk_hist(const double* __restrict__ x, int64_t m,
@@ -1861,22 +1852,33 @@ __global__ __launch_bounds__(256) void k_topk_pick(unsigned int* __restrict__ hi
         hist[b] = 0u;
     }
     __syncthreads();
-    // each thread sums its 8 consecutive bins; thread 0 walks the 256 chunk sums from the top,
-    // then the 8 bins inside the chunk that holds the k-th value
-    __shared__ unsigned int csum[256];
+    // each thread sums its 8 consecutive bins; a suffix scan over the 256 chunk sums (from the
+    // top bin down) finds the chunk that holds the k-th value in 8 steps — one thread walking
+    // them cost 8 us per level — and that chunk's thread walks its 8 bins
+    __shared__ unsigned long long suf[2][257];
     {
         unsigned int t = 0;
         for (int b = 0; b < 8; ++b) t += lh[threadIdx.x * 8 + b];
-        csum[threadIdx.x] = t;
+        suf[0][threadIdx.x] = t;
     }
+    if (threadIdx.x == 0) suf[0][256] = suf[1][256] = 0ull;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        long long krem = first ? (long long)k : stt->krem;
-        int ch = 255;
-        for (; ch > 0; --ch) {
-            if ((long long)csum[ch] >= krem) break;
-            krem -= csum[ch];
-        }
+    int cur = 0;
+    for (int off = 1; off < 256; off <<= 1) {  // suf[ch] = sum of chunks ch .. 255
+        const int src = threadIdx.x + off;
+        suf[cur ^ 1][threadIdx.x] = suf[cur][threadIdx.x] + (src < 256 ? suf[cur][src] : 0ull);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const long long k0 = first ? (long long)k : stt->krem;
+    const long long above = (long long)suf[cur][threadIdx.x + 1];  // entries in higher chunks
+    const bool mine = (long long)suf[cur][threadIdx.x] >= k0 && above < k0;
+    // k0 larger than everything counted (cannot happen for k <= m): chunk 0 takes it
+    const bool fallback0 = threadIdx.x == 0 && (long long)suf[cur][0] < k0;
+    __syncthreads();  // everyone has read stt->krem before it is rewritten
+    if (mine || fallback0) {
+        long long krem = k0 - above;
+        const int ch = threadIdx.x;
         int bin = ch * 8 + 7;
         for (; bin > ch * 8; --bin) {
             if ((long long)lh[bin] >= krem) break;
@@ -1917,12 +1919,17 @@ __global__ __launch_bounds__(256) void k_topk_scatter(const double* __restrict__
 __global__ __launch_bounds__(1024) void k_topk_finish(TopkState* __restrict__ stt,
                                                       double* __restrict__ mask,
                                                       const unsigned long long* __restrict__ lkey,
-                                                      const unsigned int* __restrict__ lidx) {
+                                                      const unsigned int* __restrict__ lidx,
+                                                      const double* __restrict__ x, int64_t m,
+                                                      int64_t k) {
     __shared__ unsigned long long sk[kTopkListCap];
     __shared__ unsigned int si[kTopkListCap];
     const unsigned int c = stt->list_count;
     if (c > (unsigned)kTopkListCap) {
+        // more entries tie with the k-th value than the list holds (massive exact ties): the
+        // exact single-block selection redoes the whole mask, here, without asking the host
         if (threadIdx.x == 0) stt->overflow = 1;
+        topk_mask_block(x, m, k, mask);
         return;
     }
     unsigned int np2 = 1;
@@ -2093,8 +2100,8 @@ bool graph_connected(const cslam_mac* mac, const double* w, double tol) {
     return comps == 1;
 }
 
-// mask of the k largest entries of x (device pointers); async on st.  The caller must check
-// tk_state->overflow after a sync and re-run with k_topk_mask when set (massive exact ties).
+// mask of the k largest entries of x (device pointers); async on st (massive exact ties are
+// handled inside k_topk_finish).
 void launch_topk(const double* x, int64_t m, int64_t k, double* mask, TopkState* stt,
                  unsigned int* hist, unsigned long long* lkey, unsigned int* lidx, hipStream_t st) {
     if (k <= 0 || k >= m) {
@@ -2109,7 +2116,7 @@ void launch_topk(const double* x, int64_t m, int64_t k, double* mask, TopkState*
     hipLaunchKernelGGL((k_topk_hist<2>), dim3(g), dim3(256), 0, st, x, m, stt, hist);
     hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(256), 0, st, hist, k, 0, stt);
     hipLaunchKernelGGL(k_topk_scatter, dim3(g), dim3(256), 0, st, x, m, stt, mask, lkey, lidx);
-    hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, st, stt, mask, lkey, lidx);
+    hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, st, stt, mask, lkey, lidx, x, m, k);
 }
 
 RowsL rows_of(const cslam_mac* mac) {
@@ -2265,6 +2272,13 @@ int clear_sticky_error(cslam_mac* mac) {
     return CSLAM_OK;
 }
 
+void note_persistent_fallback(cslam_mac* mac) {
+    if (mac->persist_fallbacks++ == 0)
+        fprintf(stderr,
+                "[cslam_hip] persistent Fiedler solver: an exchange round timed out (its workgroups "
+                "were not co-resident); redoing the solve with graph-captured launches\n");
+}
+
 // Fiedler pair of L(w) with w already on the device in mac->wvec.  Leaves theta in sc, v in x.
 int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
     Scalars h;
@@ -2278,7 +2292,7 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
         if (h.done == 4) {
             // an exchange round was not met in time (the CUs were held by someone else's
             // kernel): x is untouched, iterate with ordinary launches instead
-            mac->persist_fallbacks += 1;
+            note_persistent_fallback(mac);
             CSLAM_TRY(clear_sticky_error(mac));
         } else {
             solved = true;
@@ -2684,12 +2698,6 @@ int cslam_topk_mask(const double* x, int64_t m, int64_t k, double* mask) {
     CSLAM_HIP_TRY(hipMemcpy(sc.dx, x, m * 8, hipMemcpyHostToDevice));
     launch_topk(sc.dx, m, k, sc.dm, sc.stt, sc.hist, sc.lkey, sc.lidx, 0);
     CSLAM_HIP_TRY(hipGetLastError());
-    TopkState ts;
-    CSLAM_HIP_TRY(hipMemcpy(&ts, sc.stt, sizeof(ts), hipMemcpyDeviceToHost));
-    if (k > 0 && k < m && ts.overflow) {
-        hipLaunchKernelGGL(k_topk_mask, dim3(1), dim3(1024), 0, 0, sc.dx, m, k, sc.dm);
-        CSLAM_HIP_TRY(hipGetLastError());
-    }
     CSLAM_HIP_TRY(hipMemcpy(mask, sc.dm, m * 8, hipMemcpyDeviceToHost));
     return CSLAM_OK;
 }
@@ -2770,9 +2778,6 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
                            mac->x, m, mac->gvec);
         launch_topk(mac->gvec, m, k, mac->svec, mac->tk_state, mac->tk_hist, mac->tk_lkey,
                     mac->tk_lidx, st);
-        if (k > 0 && k < m)  // > 4096 entries tie with the k-th value: exact single-block path
-            hipLaunchKernelGGL(k_topk_mask_if_overflow, dim3(1), dim3(1024), 0, st, mac->gvec, m, k,
-                               mac->svec, mac->tk_state);
         hipLaunchKernelGGL(k_fw_dual_part, dim3(gm), dim3(256), 0, st, mac->gvec, mac->svec,
                            mac->wvec, m, mac->dual_part);
         hipLaunchKernelGGL(k_fw_dual_final, dim3(1), dim3(256), 0, st, mac->dual_part, (int)gm,
@@ -2803,7 +2808,7 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
         if (h.err == 4) {
             // an exchange round of the persistent solver timed out: redo the selection with
             // host-paced launches, from the caller's w and a fresh start vector
-            mac->persist_fallbacks += 1;
+            note_persistent_fallback(mac);
             reset_start_vector();
             std::memset(&h, 0, sizeof(h));
             h.fw_u = INFINITY;
