@@ -1,0 +1,53 @@
+"""Randomised parity sweep of the HIP kNN against the C oracle (bit-exact similarities and
+indices) over ragged shapes, k values, duplicated / zero / huge-norm rows and incremental adds.
+Not part of the test suite (minutes); run by hand:  python tools/fuzz_knn.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
+from oracle import knn as oracle_knn  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for c in range(cases):
+    dim = int(rs.choice([1, 3, 16, 17, 100, 128, 255, 256, 511, 512, 1000, 2048, 4096]))
+    n = int(rs.choice([1, 2, 15, 16, 17, 127, 128, 129, 1000, 4097, 20000]))
+    if n * dim > 40_000_000:
+        n = 40_000_000 // dim
+    m = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 64, 65, 96, 130, 300]))
+    k = int(rs.choice([1, 2, 5, 10, 128, 129, 1000]))
+    scale = float(rs.choice([1.0, 1e-3, 1e3]))
+    x = (rs.rand(n, dim).astype(np.float32) - (0.5 if rs.rand() < 0.5 else 0.0)) * scale
+    if n > 4:
+        x[rs.randint(n)] = 0.0                       # zero row
+        x[rs.randint(n)] = x[rs.randint(n)]          # duplicate
+        x[rs.randint(n)] *= 1e4
+    q = rs.rand(m, dim).astype(np.float32) - (0.5 if rs.rand() < 0.5 else 0.0)
+    if m > 2:
+        q[1] = x[rs.randint(n)]
+        q[2] = 0.0
+    pool = NearestNeighborsMatching(dim=dim)
+    cut = int(rs.randint(0, n + 1))
+    if cut:
+        pool.add_items(x[:cut], list(range(cut)))
+    for i in range(cut, min(n, cut + 3)):
+        pool.add_item(x[i], i)
+    if cut + 3 < n:
+        pool.add_items(x[cut + 3:], list(range(cut + 3, n)))
+    rows, sims = pool.search_batch(q, k)
+    oi, os_, _ = oracle_knn.search(x, q, k)
+    kk = min(k, n)
+    ok = rows.shape == (m, kk) and np.array_equal(rows, oi[:, :kk]) and \
+        np.array_equal(sims.view(np.uint32), os_[:, :kk].view(np.uint32))
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(dim=dim, n=n, m=m, k=k, scale=scale, cut=cut), flush=True)
+    pool.close()
+    if c % 25 == 0:
+        print(f"case {c}/{cases} ok so far: {c + 1 - bad}", flush=True)
+print("cases", cases, "mismatches", bad)
+sys.exit(1 if bad else 0)
