@@ -194,6 +194,8 @@ def main():
         if "fiedler_cold_device_ms" in result["extras"]:
             result["fiedler_solve_ms"] = result["extras"]["fiedler_cold_device_ms"]
             result["select_candidates_20fw_ms"] = result["extras"]["fw_subset_20iters_ms"]
+            if "acm_select_candidates_ms" in result["extras"]:   # graph assembly + MAC, end to end
+                result["acm_select_candidates_ms"] = result["extras"]["acm_select_candidates_ms"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, X, new_local, out_idx, out_sim)
 
@@ -228,8 +230,9 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     # MAC first: the solver is latency-bound, and the clocks sag for a while after the
     # 100-TFLOP/s bulk pass below
     try:
-        from cslam_amd.mac.bench_util import fiedler_bench
+        from cslam_amd.mac.bench_util import acm_select_bench, fiedler_bench
         out.update(fiedler_bench())
+        out.update(acm_select_bench())
     except ImportError:
         pass
     q1 = torch.rand((1, D), device=dev, generator=g)

@@ -75,3 +75,26 @@ def fiedler_bench(budget=500, reps=5):
     out["fw_lambda2_first_last"] = [float(mac.lambda_trace[0]), float(mac.lambda_trace[-1])]
     mac.close()
     return out
+
+
+def acm_select_bench(poses_per_robot=25_000, nb_candidates=200_000, budget=500, seed=0):
+    """End-to-end `AlgebraicConnectivityMaximization.select_candidates` at cfg3 scale: graph
+    assembly on the host + MAC create + 20 Frank-Wolfe iterations + rounding + bookkeeping —
+    what the node pays per selection round (cslam/algebraic_connectivity_maximization.py:467-542)."""
+    from ..algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
+                                                       EdgeInterRobot)
+    rs = np.random.RandomState(seed)
+    acm = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=2)
+    acm.add_fixed_edge(EdgeInterRobot(0, poses_per_robot - 1, 1, poses_per_robot - 1, acm.fixed_weight))
+    a = rs.randint(poses_per_robot, size=nb_candidates)
+    b = rs.randint(poses_per_robot, size=nb_candidates)
+    w = rs.rand(nb_candidates)
+    for i in range(nb_candidates):
+        acm.add_match(EdgeInterRobot(0, int(a[i]), 1, int(b[i]), float(w[i])))
+    n_cand = len(acm.candidate_edges)
+    with redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        selected = acm.select_candidates(budget, {0: True, 1: True})
+        dt = time.perf_counter() - t0
+    return {"acm_select_candidates_ms": dt * 1e3, "acm_candidates": n_cand, "acm_selected": len(selected),
+            "acm_solver_exceptions": acm.last_solver_exceptions}

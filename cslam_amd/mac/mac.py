@@ -11,6 +11,7 @@ RuntimeError) so the retry ladder of
 cslam/algebraic_connectivity_maximization.py:449-465 behaves the same.
 """
 import ctypes
+import itertools
 from collections import namedtuple
 
 import numpy as np
@@ -21,6 +22,15 @@ from .utils import Edge, weight_graph_lap_from_edge_list  # noqa: F401  (re-expo
 MACResult = namedtuple("MACResult", ["w", "F_unrounded", "objective_values", "duality_gaps"])
 
 
+def _edge_rows(edges):
+    """list of Edge(i, j, weight) → float64 [n, 3] in one pass (np.array on a list of namedtuples
+    is ~10x slower than this)."""
+    n = len(edges)
+    if n == 0:
+        return np.zeros((0, 3))
+    return np.fromiter(itertools.chain.from_iterable(edges), dtype=np.float64, count=3 * n).reshape(n, 3)
+
+
 class MAC:
 
     def __init__(self, fixed_measurements, candidate_measurements, num_poses, device_id=0):
@@ -29,14 +39,32 @@ class MAC:
             raise _lib.CslamHipError(_lib.CSLAM_E_NODEVICE,
                                      "no HIP device visible; cslam_amd has no CPU path")
         self.num_poses = int(num_poses)
-        self._fi = _lib.as_i32([e.i for e in fixed_measurements])
-        self._fj = _lib.as_i32([e.j for e in fixed_measurements])
-        self._fw = _lib.as_f64([e.weight for e in fixed_measurements])
-        self.weights = _lib.as_f64([e.weight for e in candidate_measurements])
-        self.edge_list = np.array([(e.i, e.j) for e in candidate_measurements],
-                                  dtype=np.int64).reshape(-1, 2)
-        self._ci = _lib.as_i32(self.edge_list[:, 0])
-        self._cj = _lib.as_i32(self.edge_list[:, 1])
+        f = _edge_rows(fixed_measurements)
+        c = _edge_rows(candidate_measurements)
+        self._init_arrays(f[:, 0], f[:, 1], f[:, 2], c[:, 0], c[:, 1], c[:, 2], device_id)
+
+    @classmethod
+    def from_arrays(cls, fixed_i, fixed_j, fixed_w, cand_i, cand_j, cand_w, num_poses, device_id=0):
+        """Same object from edge arrays (no per-edge Python objects): what
+        AlgebraicConnectivityMaximization.select_candidates hands over at cfg3 scale."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        if self._lib.cslam_device_count() <= 0:
+            raise _lib.CslamHipError(_lib.CSLAM_E_NODEVICE,
+                                     "no HIP device visible; cslam_amd has no CPU path")
+        self.num_poses = int(num_poses)
+        self._init_arrays(fixed_i, fixed_j, fixed_w, cand_i, cand_j, cand_w, device_id)
+        return self
+
+    def _init_arrays(self, fi, fj, fw, ci, cj, cw, device_id):
+        self._fi = _lib.as_i32(fi)
+        self._fj = _lib.as_i32(fj)
+        self._fw = _lib.as_f64(fw)
+        self.weights = _lib.as_f64(cw)
+        self._ci = _lib.as_i32(ci)
+        self._cj = _lib.as_i32(cj)
+        self.edge_list = np.stack([self._ci.astype(np.int64), self._cj.astype(np.int64)], axis=1) \
+            if len(self._ci) else np.zeros((0, 2), np.int64)
         self._handle = ctypes.c_void_p()
         _lib.check(self._lib.cslam_mac_create(
             self.num_poses, _lib.ptr(self._fi), _lib.ptr(self._fj), _lib.ptr(self._fw),
