@@ -265,11 +265,28 @@ def cpu_baseline(torch, X, queries, gpu_idx, gpu_sim):
     full = dt * X.shape[0] / rows
     # while we are here: the GPU's answer for the same queries restricted to the sample
     # cannot be compared directly (different row set); parity is the job of tests/.
-    return {"value": q.shape[0] / full, "unit": "candidates/s",
-            "cores": int(oracle_knn.num_threads()), "kind": "port",
-            "sample": f"{q.shape[0]} queries x {rows} of {X.shape[0]} rows x {X.shape[1]}-d, "
-                      f"k=1, OpenMP over rows; {dt:.2f} s measured, scaled x{X.shape[0] / rows:.1f} "
-                      "to the full pool"}
+    out = {"value": q.shape[0] / full, "unit": "candidates/s",
+           "cores": int(oracle_knn.num_threads()), "kind": "port",
+           "sample": f"{q.shape[0]} queries x {rows} of {X.shape[0]} rows x {X.shape[1]}-d, "
+                     f"k=1, OpenMP over rows; {dt:.2f} s measured, scaled x{X.shape[0] / rows:.1f} "
+                     "to the full pool"}
+    # second half of the metric: one Fiedler solve of the cfg3 graph on the CPU path the reference
+    # uses (networkx TraceMIN + SuperLU, restated in oracle/mac_oracle.py; single-threaded scipy)
+    try:
+        from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+        from oracle import mac_oracle
+        n, fixed, cand = cfg3_graph()
+        orc = mac_oracle.MacOracle([e.i for e in fixed], [e.j for e in fixed], [e.weight for e in fixed],
+                                   [e.i for e in cand], [e.j for e in cand], [e.weight for e in cand], n)
+        w0 = greedy_w(cand, 500)
+        t0 = time.perf_counter()
+        lam, _ = orc.evaluate_fiedler_pair(w0)
+        out["fiedler_solve_ms"] = (time.perf_counter() - t0) * 1e3
+        out["fiedler_lambda2"] = float(lam)
+        out["fiedler_sample"] = "one cold TraceMIN-LU solve of the cfg3 graph (n=50000, 500 active candidates), 1 core"
+    except Exception as e:  # the kNN baseline above stands on its own
+        out["fiedler_error"] = repr(e)
+    return out
 
 
 if __name__ == "__main__":
