@@ -954,7 +954,7 @@ struct cslam_pool {
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
     DevBuf qstage, rnq, sims, cand_a, cand_b, comp, fault;
-    DevBuf h_q, h_idx, h_sim;  // device staging of the host-pointer API
+    DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
@@ -1348,6 +1348,7 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();
+    p->h_rows.release();
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return CSLAM_OK;
@@ -1358,9 +1359,23 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, p->stream));
-    CSLAM_HIP_TRY(hipMemcpy2DAsync(p->rows + p->n * p->xs, (size_t)p->xs * sizeof(float), rows,
-                                   (size_t)p->dim * sizeof(float), (size_t)p->dim * sizeof(float),
-                                   (size_t)n_rows, hipMemcpyHostToDevice, p->stream));
+    // dense host rows → device staging with plain 1-D copies (a strided 2-D copy out of pageable
+    // memory cost ~200 us for ONE 16 KB row), then the device-side pad-and-append of add_dev;
+    // staged in chunks of at most 64 MB
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)p->dim * 4));
+    for (int64_t done = 0; done < n_rows; done += chunk_rows) {
+        const int64_t c = std::min(chunk_rows, n_rows - done);
+        const size_t bytes = (size_t)c * p->dim * sizeof(float);
+        CSLAM_TRY(p->h_rows.reserve(bytes));
+        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_rows.p, rows + done * p->dim, bytes, hipMemcpyHostToDevice,
+                                     p->stream));
+        hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, p->stream,
+                           p->h_rows.as<float>(), (int64_t)p->dim, p->dim,
+                           p->rows + (p->n + done) * p->xs, p->xs, p->dp, c);
+        CSLAM_HIP_TRY(hipGetLastError());
+        // the staging buffer is reused by the next chunk
+        if (done + c < n_rows) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     CSLAM_TRY(launch_norms(p, p->n, n_rows, p->stream));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     p->n += n_rows;
