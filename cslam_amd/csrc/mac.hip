@@ -24,7 +24,7 @@
 //
 // Two ways to run the iteration:
 //   * k_lobpcg_persistent (graphs up to 64*512*8 nodes): bootstrap + the whole loop in ONE
-//     launch of <= 64 co-resident workgroups, solver state in registers, four stamped-slot
+//     launch of <= 64 co-resident workgroups, solver state in registers, three stamped-slot
 //     exchanges per iteration (see the comment at the kernel) — ~15 us per iteration;
 //   * five small kernels per iteration captured in a hipGraph (16 iterations per replay, the
 //     host polls a `done` word between replays) — ~40 us per iteration; larger graphs, and the
@@ -937,9 +937,9 @@ __global__ __launch_bounds__(kScanThreads) void k_update_fwd_agg(
 // The solver is latency-bound (a 50k-node pose graph is ~2 MB of state): as five graph-captured
 // launches an iteration costs ~40 us, of which the arithmetic is a few us.  Here a small grid
 // (<= 64 workgroups of 512 threads, all co-resident) keeps x, p, Ax, Ap, r of its nodes in
-// REGISTERS for the whole solve and exchanges only what crosses workgroups, four times per
-// iteration — one per true global dependency: forward-sweep carries (+ the residual norm),
-// backward-sweep carries, w of the mat-vec neighbours (+ its mean), the 12 Gram sums.
+// REGISTERS for the whole solve and exchanges only what crosses workgroups, three times per
+// iteration — one per global dependency: the interface values of the partitioned tridiagonal
+// solve (+ the residual norm), w of the mat-vec neighbours (+ its mean), the 12 Gram sums.
 //
 // Exchange = STAMPED SLOTS, no barrier and no fence: every exchanged double travels in a 16-byte
 // slot {value, stamp} written with ONE agent-scope (sc1, write-through) 16-byte store and read
@@ -1050,8 +1050,9 @@ struct PArgs {
 };
 
 // slot offsets inside the exchange buffer; every array is [2 parities][...]
-constexpr int kSlotXfM = 0, kSlotXfC = 2 * kPMaxBlocks, kSlotXbM = 4 * kPMaxBlocks,
-              kSlotXbC = 6 * kPMaxBlocks, kSlotPs = 8 * kPMaxBlocks, kSlotRp = 10 * kPMaxBlocks,
+constexpr int kSlotY = 0, kSlotZ = 2 * kPMaxBlocks,  // [2][B]: yloc_e, zA_s of the partitioned solve
+              kSlotCphi = 4 * kPMaxBlocks, kSlotCzf = 5 * kPMaxBlocks,  // [B] each: per-solve constants
+              kSlotCpsi = 6 * kPMaxBlocks, kSlotPs = 8 * kPMaxBlocks, kSlotRp = 10 * kPMaxBlocks,
               kSlotPt = 12 * kPMaxBlocks /* [2][12][kPMaxBlocks] */,
               kSlotW = 36 * kPMaxBlocks /* [2][wstride] */;
 
@@ -1124,30 +1125,6 @@ __device__ inline void block_scan_p(Aff t, Aff* swave /* [kPWaves] */, Aff& excl
     excl = REV ? Aff{wave_reverse(ex.m), wave_reverse(ex.c)} : ex;
 }
 
-// value entering workgroup b in sweep order: the composites of the workgroups before it applied
-// to 0.  One wave: lane j polls workgroup j's composite (both slots in flight together), then a
-// shuffle scan over the 64 lanes.
-template <bool REV>
-__device__ inline double fold_incoming(SlotBuf rs, int slot_m, int slot_c, int nb, int b,
-                                       double stamp, int& ok) {
-    const int lane = threadIdx.x & 63;
-    const int j = REV ? 63 - lane : lane;  // workgroup this lane polls
-    Aff v{1.0, 0.0};
-    if (j < nb) {
-        d2 vm = ld_slot(rs, slot_m + j), vc = ld_slot(rs, slot_c + j);
-        poll_slots2(rs, slot_m + j, slot_c + j, true, vm, vc, stamp, ok);
-        v.m = vm.x;
-        v.c = vc.x;
-    }
-    // sweep order ascending in lanes: for the backward sweep lane j takes workgroup 63 - j
-    // (lanes of absent workgroups hold the identity, wherever they sit)
-    v = wave_scan_aff(v);
-    const int src = REV ? 63 - (b + 1) : b - 1;
-    const bool none = REV ? (b + 1 >= nb) : (b == 0);
-    const double r = lane_bcast_dyn(v.c, src & 63);
-    return none ? 0.0 : r;
-}
-
 // sum over workgroups of one published double per workgroup (lane j of the calling wave polls
 // workgroup j; every lane returns the sum)
 __device__ inline double fold_sum(SlotBuf rs, int slot, int nb, double stamp, int& ok) {
@@ -1184,7 +1161,7 @@ __device__ inline double block_sum_p(const double (&v)[NV], double* sred) {
 
 template <int E>
 __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
-    __shared__ Aff swave[kPWaves];
+    __shared__ Aff swave[kPWaves], swave_b[kPWaves];  // forward / backward block scans
     __shared__ double sred[12 * kPWaves];
     __shared__ double s_vin, s_res, s_vinb, s_mu, s_g[12];
     __shared__ int s_ovw[kPWaves], s_ov_pos[kPOverflow * kPT], s_ov_own[kPOverflow * kPT];
@@ -1249,8 +1226,80 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         }
         if (!__syncthreads_and(ok)) done = 4;
     }
-    Aff excl_f{1.0, 0.0}, tot;
+    // ---- partitioned tridiagonal solve (M z = r with M = L D L^T, one exchange round) ---------
+    // Inside workgroup b (nodes s..e) the forward sweep is y_i = yloc_i + phi_i * Y_{s-1} and the
+    // backward sweep z_i = zA_i + Y_{s-1} * zF_i + Z_{e+1} * psi_i, where yloc / zA are the sweeps
+    // with zero incoming values and
+    //   phi_i = prod_{k=s-1}^{i-1} (-l_k),   zF = backward sweep of phi * invd,
+    //   psi_i = prod_{k=i}^{e} (-l_k)
+    // depend on the factorisation only.  A workgroup therefore does BOTH local sweeps straight
+    // after the Ritz update and publishes two scalars (yloc_e, zA_s); everybody then folds the
+    // two scalar recurrences  Y_e(b) = yloc_e(b) + phi_e(b) Y_e(b-1)  and
+    // Z_s(b) = zA_s(b) + Y_e(b-1) zF_s(b) + psi_s(b) Z_s(b+1)  with two wave scans and corrects
+    // its nodes — instead of one exchange round per sweep.
+    Aff tot;
+    double zA[E], phi[E], zF[E], psi[E];
+    auto local_sweeps = [&](double& yloc_e, double& zA_s) {
+        Aff t{1.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e) t = compose(t, Aff{-lprev[e], r[e]});
+        Aff ex;
+        block_scan_p<false>(t, swave, ex, tot);
+        yloc_e = tot.c;
+        double yl[E];
+        double v = ex.c;  // zero incoming value
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            v = r[e] - lprev[e] * v;
+            yl[e] = v;
+        }
+        Aff tb{1.0, 0.0};
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) tb = compose(tb, Aff{-lcur[e], yl[e] * idv[e]});
+        block_scan_p<true>(tb, swave_b, ex, tot);
+        zA_s = tot.c;
+        v = ex.c;
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) {
+            v = yl[e] * idv[e] - lcur[e] * v;
+            zA[e] = v;
+        }
+    };
+    double c_phi = 1.0, c_zf = 0.0, c_psi = 1.0;  // wave 0, lane j: constants of workgroup j
     if (!done) {
+        // constants of this factorisation
+        {
+            Aff t{1.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < E; ++e) t = compose(t, Aff{-lprev[e], 0.0});
+            Aff ex;
+            block_scan_p<false>(t, swave, ex, tot);
+            const double phi_e = tot.m;
+            double m = ex.m;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                m = -lprev[e] * m;
+                phi[e] = m;
+            }
+            Aff tb{1.0, 0.0};
+#pragma unroll
+            for (int e = E - 1; e >= 0; --e) tb = compose(tb, Aff{-lcur[e], phi[e] * idv[e]});
+            block_scan_p<true>(tb, swave_b, ex, tot);
+            double v = ex.c, mm = ex.m;
+#pragma unroll
+            for (int e = E - 1; e >= 0; --e) {
+                v = phi[e] * idv[e] - lcur[e] * v;
+                zF[e] = v;
+                mm = -lcur[e] * mm;
+                psi[e] = mm;
+            }
+            if (tid == 0) {
+                st_slot(xb, kSlotCphi + b, phi_e, stamp0);
+                st_slot(xb, kSlotCzf + b, tot.c, stamp0);
+                st_slot(xb, kSlotCpsi + b, tot.m, stamp0);
+            }
+        }
+        // bootstrap Rayleigh-Ritz, first residual, its local sweeps
         double g[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) g[q] = 0.0;
@@ -1258,23 +1307,28 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         g[6] = s_g[6];
         double coef[3];
         if (!rr_step(g, coef, theta)) done = 2;
-        Aff t{1.0, 0.0};
         double rs[1] = {0.0};
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             x[e] *= coef[0];
             Ax[e] *= coef[0];
             r[e] = Ax[e] - theta * x[e];
-            t = compose(t, Aff{-lprev[e], r[e]});
             rs[0] += fabs(r[e]);
         }
-        // composites of the first forward sweep + ||r||_1 → iteration 0's inputs
-        block_scan_p<false>(t, swave, excl_f, tot);
+        double yloc_e, zA_s;
+        local_sweeps(yloc_e, zA_s);
         const double bs = block_sum_p<1>(rs, sred);
         if (tid == 0 && !done) {
-            st_slot(xb, kSlotXfM + kPMaxBlocks + b, tot.m, stamp0 + 1.0);
-            st_slot(xb, kSlotXfC + kPMaxBlocks + b, tot.c, stamp0 + 1.0);
+            st_slot(xb, kSlotY + kPMaxBlocks + b, yloc_e, stamp0 + 1.0);
+            st_slot(xb, kSlotZ + kPMaxBlocks + b, zA_s, stamp0 + 1.0);
             st_slot(xb, kSlotRp + kPMaxBlocks + b, bs, stamp0 + 1.0);
+        }
+        if (wave == 0 && lane < nb) {   // everybody's constants, once per solve
+            d2 v0 = ld_slot(xb, kSlotCphi + lane), v1 = ld_slot(xb, kSlotCzf + lane);
+            poll_slots2(xb, kSlotCphi + lane, kSlotCzf + lane, true, v0, v1, stamp0, ok);
+            c_phi = v0.x;
+            c_zf = v1.x;
+            c_psi = poll_slot(xb, kSlotCpsi + lane, ld_slot(xb, kSlotCpsi + lane), stamp0, ok);
         }
     }
     // Row i of L(w) = chain terms (weights in registers; w of i-1 / i+1 comes from this thread's
@@ -1375,10 +1429,27 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         const int par = (k + 1) & 1;
         const int xo = par * kPMaxBlocks;
 
-        // ---- A: residual norm + forward carries of every workgroup (published by D / above)
+        // ---- A: residual norm + the interface values of the partitioned solve (published by D /
+        //         above): two scalar recurrences over the workgroups, folded by one wave
         if (wave == 0) {
-            const double v = fold_incoming<false>(xb, kSlotXfM + xo, kSlotXfC + xo, nb, b, stamp, ok);
-            if (lane == 0) s_vin = v;
+            d2 vy{0.0, stamp}, vz{0.0, stamp};
+            if (lane < nb) {
+                vy = ld_slot(xb, kSlotY + xo + lane);
+                vz = ld_slot(xb, kSlotZ + xo + lane);
+                poll_slots2(xb, kSlotY + xo + lane, kSlotZ + xo + lane, true, vy, vz, stamp, ok);
+            }
+            // Y_e(j): forward recurrence, ascending j = ascending lanes
+            const Aff fy = wave_scan_aff(Aff{c_phi, lane < nb ? vy.x : 0.0});
+            const double yin = dpp_mov<kDppWaveShr1>(fy.c, 0.0);      // Y_e(j - 1)
+            // Z_s(j): backward recurrence, descending j = ascending lanes after a reversal
+            const double cz = lane < nb ? vz.x + yin * c_zf : 0.0;
+            const Aff bz = wave_scan_aff(Aff{wave_reverse(c_psi), wave_reverse(cz)});
+            const double y_b = lane_bcast_dyn(yin, b);
+            const double z_b = b + 1 < nb ? lane_bcast_dyn(bz.c, 63 - (b + 1)) : 0.0;
+            if (lane == 0) {
+                s_vin = y_b;
+                s_vinb = z_b;
+            }
         } else if (wave == 1) {
             const double v = fold_sum(xb, kSlotRp + xo, nb, stamp, ok);
             if (lane == 0) s_res = v;
@@ -1397,46 +1468,17 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         if (!(res == res)) done = 2;
         if (done) break;
         iters += 1;
-
-        // forward apply, backward composites
-        double y[E];
-        Aff excl_b;
-        {
-            double v = excl_f.m * s_vin + excl_f.c;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                v = r[e] - lprev[e] * v;
-                y[e] = v;
-            }
-            Aff t{1.0, 0.0};
-#pragma unroll
-            for (int e = E - 1; e >= 0; --e) t = compose(t, Aff{-lcur[e], y[e] * idv[e]});
-            block_scan_p<true>(t, swave, excl_b, tot);
-            if (tid == 0) {
-                st_slot(xb, kSlotXbM + xo + b, tot.m, stamp);
-                st_slot(xb, kSlotXbC + xo + b, tot.c, stamp);
-            }
-        }
         PTICK(1);
-
-        // ---- B: backward carries → w (published per node: the mat-vec gathers neighbours)
-        if (wave == 0) {
-            const double v = fold_incoming<true>(xb, kSlotXbM + xo, kSlotXbC + xo, nb, b, stamp, ok);
-            if (lane == 0) s_vinb = v;
-        }
-        if (!__syncthreads_and(ok)) {
-            done = 4;
-            break;
-        }
         PTICK(2);
+        // w = M^-1 r (published per node where the mat-vec of another thread gathers it)
         double w[E];
         const int wslot = kSlotW + par * (int)a.wstride;
         {
-            double v = excl_b.m * s_vinb + excl_b.c;
+            const double yin = s_vin, zin = s_vinb;
             double ws[1] = {0.0};
 #pragma unroll
             for (int e = E - 1; e >= 0; --e) {
-                v = y[e] * idv[e] - lcur[e] * v;
+                const double v = zA[e] + yin * zF[e] + zin * psi[e];
                 w[e] = v;
                 ws[0] += v;
                 if (publish[e]) st_slot(xb, wslot + i0 + e, v, stamp);
@@ -1635,7 +1677,6 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 done = 2;
                 break;
             }
-            Aff t{1.0, 0.0};
             double rs[1] = {0.0};
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1651,14 +1692,14 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 const double ri = axn - theta * xn;
                 r[e] = ri;
                 rs[0] += fabs(ri);
-                t = compose(t, Aff{-lprev[e], ri});
             }
-            block_scan_p<false>(t, swave, excl_f, tot);
+            double yloc_e, zA_s;
+            local_sweeps(yloc_e, zA_s);
             const double bs = block_sum_p<1>(rs, sred);
             if (tid == 0) {
                 const int xn = (par ^ 1) * kPMaxBlocks;
-                st_slot(xb, kSlotXfM + xn + b, tot.m, stamp + 1.0);
-                st_slot(xb, kSlotXfC + xn + b, tot.c, stamp + 1.0);
+                st_slot(xb, kSlotY + xn + b, yloc_e, stamp + 1.0);
+                st_slot(xb, kSlotZ + xn + b, zA_s, stamp + 1.0);
                 st_slot(xb, kSlotRp + xn + b, bs, stamp + 1.0);
             }
         }
