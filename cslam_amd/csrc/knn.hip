@@ -635,7 +635,8 @@ __global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gemm32: raw dots for MANY queries (the MFMA-bound regime, >= 96 queries per call).
+// k_gemm32: raw dots for MANY queries (the MFMA-bound regime: from ~128 queries per call, see
+// the cost model in compute_dots).
 //   LDS-tiled fp32 GEMM on v_mfma_f32_32x32x2_f32: block = 4 waves (2 x 2), block tile
 //   128 rows x 128 queries, K step = one 16-float block; every wave owns 64 x 64 outputs as
 //   2 x 2 MFMA tiles.  The canonical chain order of DESIGN.md §3 maps onto the 2-slot MFMA as
@@ -1030,9 +1031,11 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
                 hipStream_t st) {
     static const int wpc_env = getenv("CSLAM_SCAN_WPC") ? atoi(getenv("CSLAM_SCAN_WPC")) : 0;
     static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
-    const int wpc = wpc_env > 0 ? wpc_env : 4;  // waves per CU (profiles/r01_scan_sweep*.txt)
+    // waves per CU and strips per wave of the variant that will run (profiles/r01_scan_sweep*.txt,
+    // r01_scan_m_sweep.txt): 17..32 queries <T=2,S=8,U=4> at 4 waves/CU, 33..64 <T=4,S=4,U=4> at 8
+    const int wpc = wpc_env > 0 ? wpc_env : (m > 32 ? 8 : 4);
     const int S = (s_env == 1 || s_env == 2 || s_env == 4 || s_env == 16) ? s_env : 8;  // strips per query fragment (T = 1)
-    const int s_eff = (m <= 16) ? S : 4;
+    const int s_eff = (m <= 16) ? S : (m <= 32 ? 8 : 4);
     int64_t groups = (p->vn + 16 * s_eff - 1) / (16 * s_eff);
     int64_t resident = (int64_t)p->cus * wpc;
     int64_t n_waves = groups < resident ? groups : resident;
@@ -1122,9 +1125,9 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
                 launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
         }
     } else if (m <= 32) {
-        launch_scan_u<2, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        launch_scan_u<2, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
     } else {
-        launch_scan_u<4, 4, 2>(p, Qstage, m, dots, dots_stride, n_waves, st);
+        launch_scan_u<4, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
     }
     CSLAM_HIP_TRY(hipGetLastError());
     if (prof) {
@@ -1147,7 +1150,16 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
                                          (size_t)(kQueryChunk + 128) * p->dp) * sizeof(float)));
     CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
     static const int gemm_env = getenv("CSLAM_GEMM") ? atoi(getenv("CSLAM_GEMM")) : 1;
-    if (gemm_env && m >= 96 && p->vn > 0) {
+    // Scan passes or the 128-query GEMM tiles?  Relative costs measured at 100k x 4096
+    // (profiles/r01_scan_m_sweep.txt; one 16-query pass = 1): a 32-query pass 1.12, a 64-query
+    // pass 1.85, a GEMM tile 3.2.  The scan wins up to ~200 queries except where the tiles fit
+    // exactly (128), the GEMM beyond.
+    auto scan_cost = [](int mm) {
+        const int rem = mm % 64;
+        return 1.85 * (mm / 64) + (rem == 0 ? 0.0 : rem <= 16 ? 1.0 : rem <= 32 ? 1.12 : 1.85);
+    };
+    const bool use_gemm = gemm_env && m >= 96 && p->vn > 0 && 3.2 * ((m + 127) / 128) < scan_cost(m);
+    if (use_gemm) {
         // MFMA-bound regime: stage the whole chunk once (padded to 128-query tiles), one GEMM
         const int mq_pad = (m + 127) / 128 * 128;
         CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
