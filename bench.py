@@ -242,6 +242,10 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     out["search_best_1query_ms"] = t * 1e3
     t = timed(q16, 10, 50)
     out["search_16queries_k10_ms"] = t * 1e3
+    for mq in (32, 64):      # mid-size batches: the T=2 / T=4 scan variants
+        tq = timed(torch.rand((mq, D), device=dev, generator=g), 1, 30)
+        out[f"search_{mq}queries_ms"] = tq * 1e3
+        out[f"search_{mq}queries_candidates_per_s"] = mq / tq
     t = timed(q1024, 1, 3)
     out["bulk_1024queries_ms"] = t * 1e3
     out["bulk_1024queries_candidates_per_s"] = 1024 / t
