@@ -155,11 +155,17 @@ def main():
     #   pool rows N*D*4 + staged queries M*D*4 + results M*k*8
     alg_bytes = N * D * 4 + gathered_rows * D * 4 + gathered_rows * 1 * 8
     achieved = alg_bytes / (scan_ms.value * 1e-3) / 1e9 if scan_ms.value > 0 else 0.0
+    # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes
+    # (tools/pmc_traffic.sh) and summarised in profiles/r02_scan_pmc.json; it is only quoted
+    # when that summary is about the kernel variant that ran here
+    scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_scan_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_scan_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            if rec.get("kernel") == scan_kernel and rec.get("keyframes") == N and rec.get("dim") == D:
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -182,8 +188,9 @@ def main():
                    "k": 1, "parallelism": f"robot-per-gpu x{world}"
                                           + (" + RCCL all-gather of new descriptors, overlapped "
                                              "with the previous step's scan" if world > 1 else "")},
-        "roofline": {"bound": "hbm", "kernel": "k_scan<T=1,S=8,U=4,G=4>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_of_measured_copy_peak": achieved / 6290.0,
                      "traffic": traffic, "avg_kernel_ms": scan_ms.value,
                      "launches_timed": n_l.value, "algorithmic_bytes_per_launch": alg_bytes},
     }

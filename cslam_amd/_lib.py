@@ -60,6 +60,7 @@ SIGNATURES = {
     "cslam_pool_similarities_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int64, _vp]),
     "cslam_pool_profile_begin": (_c.c_int, [_vp, _c.c_int]),
     "cslam_pool_profile_end": (_c.c_int, [_vp, _f64p, _c.POINTER(_c.c_int)]),
+    "cslam_pool_scan_kernel": (_c.c_char_p, [_vp]),
     "cslam_mac_create": (_c.c_int, [_c.c_int32, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp,
                                     _c.c_int64, _c.c_int, _c.POINTER(_vp)]),
     "cslam_mac_destroy": (_c.c_int, [_vp]),

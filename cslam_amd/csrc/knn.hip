@@ -635,6 +635,218 @@ __global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_scan_dma<NS,NW,NST,AUX>: the HBM-bound scan (<= 16 queries) with X streamed through LDS-DMA.
+//   Why: the MFMA A-operand shape (16 rows x 64 B per load instruction) touches 16 half lines
+//   per instruction and tops out at 5.1-5.3 TB/s in k_scan; a linear 1-KiB-per-instruction
+//   read streams at 6.0-6.3 TB/s on this part (profiles/r02_dma_scan_probe.txt).  Here every
+//   global_load_lds_dwordx4 moves ONE row's 256-float slice (8 whole lines) straight into LDS,
+//   and the wave reads the A fragments back with ds_read_b128 (row pitch 1024+32 B: the 16-lane
+//   groups of ds_read_b128 hit 16 different 16-B slots, conflict free).
+//   Structure: NW waves per block, one block per CU, NO barriers: every wave owns a private
+//   ring of NST stages (stage = 16 rows x 256 floats) and only its own counted vmcnt orders its
+//   ds_reads behind its DMAs.  A stage is read into 64 VGPRs at once and its slot re-issued
+//   immediately, so a wave keeps NST-1..NST stages (16..32 KiB at NST=2) in flight.
+//   Work order is k-slice-major inside a row panel (<= NS strips): the B fragments (queries) of
+//   a 256-float slice sit in 64 VGPRs and serve all NS strips, so the L2 query stream is 1/NS
+//   of the X stream; the next slice's fragments are prefetched by inline-asm global loads that
+//   the compiler's waitcnt pass does not see (an ordinary load beside LDS-DMAs makes hipcc
+//   drain vmcnt(0)), counted by hand together with the DMA pieces.
+//   Numerics: per (row, query) the MFMA chain visits k in the canonical order, accumulators
+//   are carried per strip across the two slices of a 512-float chunk and folded exactly like
+//   k_scan -> identical bits (tests/test_knn_gpu.py).
+//   Requires dp % 256 == 0 (the host falls back to k_scan otherwise).
+// ---------------------------------------------------------------------------------------------
+constexpr int kDmaPieceB = 1024 + 32;          // bytes per row piece in LDS
+constexpr int kDmaStageB = 16 * kDmaPieceB;    // 16 rows x 256 floats
+constexpr int64_t kDmaMinRows = 16384;         // below this the register-ring kernel is used
+
+__device__ inline void wait_vm_dyn(int n) {
+    // s_waitcnt takes an immediate: wave-uniform switch over the exact count (vmcnt is 6 bits;
+    // more than 48 younger operations cannot hide anything that is still needed here)
+#define CSLAM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        CSLAM_W(0) CSLAM_W(1) CSLAM_W(2) CSLAM_W(3) CSLAM_W(4) CSLAM_W(5) CSLAM_W(6) CSLAM_W(7)
+        CSLAM_W(8) CSLAM_W(9) CSLAM_W(10) CSLAM_W(11) CSLAM_W(12) CSLAM_W(13) CSLAM_W(14)
+        CSLAM_W(15) CSLAM_W(16) CSLAM_W(17) CSLAM_W(18) CSLAM_W(19) CSLAM_W(20) CSLAM_W(21)
+        CSLAM_W(22) CSLAM_W(23) CSLAM_W(24) CSLAM_W(25) CSLAM_W(26) CSLAM_W(27) CSLAM_W(28)
+        CSLAM_W(29) CSLAM_W(30) CSLAM_W(31) CSLAM_W(32) CSLAM_W(33) CSLAM_W(34) CSLAM_W(35)
+        CSLAM_W(36) CSLAM_W(37) CSLAM_W(38) CSLAM_W(39) CSLAM_W(40) CSLAM_W(41) CSLAM_W(42)
+        CSLAM_W(43) CSLAM_W(44) CSLAM_W(45) CSLAM_W(46) CSLAM_W(47) CSLAM_W(48)
+        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    }
+#undef CSLAM_W
+}
+
+// 16 B fragments (one 256-float slice of the lane's query column) by inline-asm loads; the
+// registers may only be read behind a counted wait followed by tie16()
+__device__ inline void load_b16(f32x4 (&b)[16], const float* qrow) {
+#define CSLAM_LB(I)                                                                     \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:" #I "*64" : "=v"(b[I]) : "v"(qrow) : "memory");
+    CSLAM_LB(0) CSLAM_LB(1) CSLAM_LB(2) CSLAM_LB(3) CSLAM_LB(4) CSLAM_LB(5) CSLAM_LB(6) CSLAM_LB(7)
+    CSLAM_LB(8) CSLAM_LB(9) CSLAM_LB(10) CSLAM_LB(11) CSLAM_LB(12) CSLAM_LB(13) CSLAM_LB(14) CSLAM_LB(15)
+#undef CSLAM_LB
+}
+__device__ inline void tie16(f32x4 (&b)[16]) {
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
+                      "+v"(b[6]), "+v"(b[7]));
+    asm volatile("" : "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]),
+                      "+v"(b[14]), "+v"(b[15]));
+}
+
+struct DmaCursor {   // position of a stage in a wave's work list
+    int64_t lo;      // first row of the panel
+    int rows;        // rows of the panel (<= 16 * NS)
+    int ns;          // strips of the panel
+    int p;           // panel index
+    int kc;          // 256-float slice
+    int s;           // strip inside the panel
+};
+
+template <int NS, int NW, int NST, int AUX>
+__global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
+                                                      int64_t n, int dp,
+                                                      const float* __restrict__ Q, int m_valid,
+                                                      float* __restrict__ dots,
+                                                      int64_t dots_stride, int n_panels, int ppw) {
+    extern __shared__ __attribute__((aligned(16))) char dma_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: uniform branches
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x * NW + wave;
+    char* ring = dma_lds + wave * NST * kDmaStageB;
+    const int nkc = dp >> 8;
+    const int p_begin = w * ppw;
+    int p_end = p_begin + ppw;
+    if (p_end > n_panels) p_end = n_panels;
+    if (p_begin >= p_end) return;
+
+    auto panel = [&](DmaCursor& c, int p) {
+        c.p = p;
+        c.lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        c.rows = (int)(hi - c.lo);
+        c.ns = (c.rows + 15) >> 4;
+        c.kc = 0;
+        c.s = 0;
+    };
+    auto advance = [&](DmaCursor& c) {
+        if (++c.s < c.ns) return;
+        c.s = 0;
+        if (++c.kc < nkc) return;
+        panel(c, c.p + 1);  // may run to p_end: the caller checks before issuing
+    };
+    // one DMA instruction per valid row of the strip: lane l moves bytes [16l, 16l+16) of the
+    // row's slice, the LDS image of a piece is linear (base + 16 * lane)
+    auto issue = [&](const DmaCursor& c, char* slot) {
+        int cnt = c.rows - 16 * c.s;
+        cnt = cnt > 16 ? 16 : cnt;
+        const float* src = X + (c.lo + 16 * c.s) * xs + c.kc * 256 + lane * 4;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+            if (rr < cnt)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + rr * xs),
+                    (__attribute__((address_space(3))) void*)(slot + rr * kDmaPieceB), 16, 0, AUX);
+        return cnt;
+    };
+
+    const float* qrow = Q + (int64_t)r * dp + 4 * g;  // this lane's B fragment column
+    f32x4 bc[16], bn[16];
+    DmaCursor ic;  // issue cursor: runs NST stages ahead of the consumer
+    panel(ic, p_begin);
+    int y[NST];  // vector-memory operations issued after the stage that sits in slot i
+    int yq = 0;  // ... after the B loads in flight
+#pragma unroll
+    for (int i = 0; i < NST; ++i) y[i] = 0;
+    auto bump = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) y[i] += k;
+        yq += k;
+    };
+    load_b16(bn, qrow);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie16(bn);
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (ic.p < p_end) {
+            const int c = issue(ic, ring + i * kDmaStageB);
+            bump(c);
+            y[i] = 0;
+            advance(ic);
+        }
+
+    int slot = 0;  // ring slot of the stage the consumer is at
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        const int ns = (int)((hi - lo + 15) >> 4);
+        f32x4 acc[NS], tot[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int kc = 0; kc < nkc; ++kc) {
+            // bn holds B(kc), landed and tied: hand it over and start B(kc+1) (slice 0 again for
+            // the next panel); it is waited for at the end of this slice
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
+            bump(16);
+            yq = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    char* sp = ring + slot * kDmaStageB;
+                    int yc = y[0];
+#pragma unroll
+                    for (int i = 1; i < NST; ++i) yc = slot == i ? y[i] : yc;
+                    wait_vm_dyn(yc);  // this stage's pieces have landed
+                    f32x4 a[16];
+                    const char* ap = sp + r * kDmaPieceB + g * 16;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 64);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ic.p < p_end) {  // the slot is free again: refill it NST stages ahead
+                        const int c = issue(ic, sp);
+                        advance(ic);
+                        bump(c);
+#pragma unroll
+                        for (int i = 0; i < NST; ++i) y[i] = slot == i ? 0 : y[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bc[i][j], acc[s],
+                                                                          0, 0, 0);
+                    if ((kc & 1) || kc + 1 == nkc) {  // end of a 512-float chunk / of the row
+                        tot[s] = tot[s] + acc[s];
+                        acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    slot = slot + 1 == NST ? 0 : slot + 1;
+                }
+            }
+            wait_vm_dyn(yq);
+            tie16(bn);
+        }
+        if (r < m_valid) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    const int64_t r0 = lo + 16 * s + 4 * g;
+                    float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (r0 + e < hi) out[e] = tot[s][e];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_gemm32: raw dots for MANY queries (the MFMA-bound regime: from ~128 queries per call, see
 // the cost model in compute_dots).
 //   LDS-tiled fp32 GEMM on v_mfma_f32_32x32x2_f32: block = 4 waves (2 x 2), block tile
@@ -960,9 +1172,30 @@ struct cslam_pool {
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
     bool prof_on = false;
+    const char* last_scan_kernel = "";  // variant of the last dots kernel launched (bench.py)
+    // ordering between the device-pointer API (caller's stream) and the host-pointer API (the
+    // pool's own non-blocking stream): every *_dev call records dev_ev on its stream, the next
+    // call on a different stream waits for it first
+    hipEvent_t dev_ev = nullptr;
+    hipStream_t dev_stream = nullptr;
+    bool dev_pending = false;
 };
 
 namespace {
+
+// make `st` wait for the last device-API work enqueued on another stream
+int order_after_dev(cslam_pool* p, hipStream_t st) {
+    if (p->dev_pending && p->dev_stream != st)
+        CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->dev_ev, 0));
+    return CSLAM_OK;
+}
+// remember that device-API work is in flight on `st`
+int mark_dev(cslam_pool* p, hipStream_t st) {
+    CSLAM_HIP_TRY(hipEventRecord(p->dev_ev, st));
+    p->dev_stream = st;
+    p->dev_pending = true;
+    return CSLAM_OK;
+}
 
 int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     if (want_rows <= p->cap) return CSLAM_OK;
@@ -1049,7 +1282,48 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         // HBM latencies; kept for A/B runs, profiles/r01_scan_lds_vs_ring.txt)
         const bool use_lds = kern_env && strcmp(kern_env, "lds") == 0;
         const bool use_pc = kern_env && strcmp(kern_env, "pc") == 0;
-        if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
+        // X through LDS-DMA (k_scan_dma, 5.9-6.1 TB/s) for pools that are worth it; "ring"
+        // keeps the register-ring kernel, "dma" forces the DMA kernel wherever it is legal
+        const bool force_dma = kern_env && strcmp(kern_env, "dma") == 0;
+        const bool use_dma = p->dp % 256 == 0 && p->vn > 0 && !use_lds && !use_pc &&
+                             (force_dma || (!(kern_env && strcmp(kern_env, "ring") == 0) &&
+                                            p->vn >= kDmaMinRows));
+        if (use_dma) {
+            constexpr int NS = 8, NW = 4, NST = 2;
+            const int64_t nw = (int64_t)p->cus * NW;
+            int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
+            if (ppw < 1) ppw = 1;
+            int64_t n_panels = nw * ppw;
+            const int64_t strips = (p->vn + 15) / 16;
+            if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
+            const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
+            const size_t lds = (size_t)NW * NST * kDmaStageB;
+            // pool rows are read once per search: non-temporal unless the pool could stay
+            // resident in the 256-MiB Infinity Cache between searches
+            const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
+#define CSLAM_DMA_LAUNCH(AUX)                                                                     \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX>,          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds));                                         \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX>), dim3(blocks), dim3(NW * 64), lds, st,  \
+                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,         \
+                           dots_stride, (int)n_panels, (int)ppw);                                 \
+    } while (0)
+            if (nt) {
+                CSLAM_DMA_LAUNCH(2);
+                p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt>";
+            } else {
+                CSLAM_DMA_LAUNCH(0);
+                p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2>";
+            }
+#undef CSLAM_DMA_LAUNCH
+        } else if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
+            p->last_scan_kernel = "k_scan_pc";
             static const int ps_env = getenv("CSLAM_SCAN_PS") ? atoi(getenv("CSLAM_SCAN_PS")) : 0;
             static const int pw_env = getenv("CSLAM_SCAN_PW") ? atoi(getenv("CSLAM_SCAN_PW")) : 0;
             const int PS = ps_env == 1 ? 1 : 2;
@@ -1086,6 +1360,7 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
             else CSLAM_PC_LAUNCH(2, 8);
 #undef CSLAM_PC_LAUNCH
         } else if (use_lds) {
+            p->last_scan_kernel = "k_scan_lds";
             static const int ls_env = getenv("CSLAM_SCAN_LS") ? atoi(getenv("CSLAM_SCAN_LS")) : 0;
             static const int bpc_env = getenv("CSLAM_SCAN_BPC") ? atoi(getenv("CSLAM_SCAN_BPC")) : 0;
             const int LS = ls_env == 2 ? 2 : 1;
@@ -1109,6 +1384,7 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         } else {
             static const int u_env = getenv("CSLAM_SCAN_U") ? atoi(getenv("CSLAM_SCAN_U")) : 0;
             const int U = u_env == 8 ? 8 : 4;
+            p->last_scan_kernel = "k_scan<T=1> (register ring)";
             if (S == 1 && U == 8)
                 launch_scan_u<1, 1, 8>(p, Qstage, m, dots, dots_stride, n_waves, st);
             else if (S == 2 && U == 8)
@@ -1125,8 +1401,10 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
                 launch_scan_u<1, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
         }
     } else if (m <= 32) {
+        p->last_scan_kernel = "k_scan<T=2,S=8,U=4>";
         launch_scan_u<2, 8, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
     } else {
+        p->last_scan_kernel = "k_scan<T=4,S=4,U=4>";
         launch_scan_u<4, 4, 4>(p, Qstage, m, dots, dots_stride, n_waves, st);
     }
     CSLAM_HIP_TRY(hipGetLastError());
@@ -1173,6 +1451,7 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
         bool prof = p->prof_on && p->prof_n < p->prof_max;
         if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+        p->last_scan_kernel = "k_gemm32";
         hipLaunchKernelGGL(k_gemm32, dim3((unsigned)nblocks), dim3(256), 0, st,
                            p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, p->qstage.as<float>(), m,
                            dots, dots_stride, n_rowblk, n_colblk);
@@ -1334,6 +1613,11 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
         delete p;
         return fail(CSLAM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipEventCreateWithFlags(&p->dev_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        cslam_pool_destroy(p);
+        return fail(CSLAM_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+    }
     rc = pool_grow(p, capacity_hint > 0 ? capacity_hint : 1000, p->stream);
     if (rc != CSLAM_OK) {
         cslam_pool_destroy(p);
@@ -1346,7 +1630,9 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
 int cslam_pool_destroy(cslam_pool_t* p) {
     if (!p) return CSLAM_OK;
     (void)hipSetDevice(p->device);
+    if (p->dev_pending) (void)hipEventSynchronize(p->dev_ev);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->dev_ev) (void)hipEventDestroy(p->dev_ev);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->rows) (void)hipFree(p->rows);
     if (p->inv_norm) (void)hipFree(p->inv_norm);
@@ -1370,6 +1656,7 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
     if (!p || (!rows && n_rows > 0) || n_rows < 0) return fail(CSLAM_E_INVALID, "pool_add: bad args");
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_TRY(order_after_dev(p, p->stream));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, p->stream));
     // dense host rows → device staging with plain 1-D copies (a strided 2-D copy out of pageable
     // memory cost ~200 us for ONE 16 KB row), then the device-side pad-and-append of add_dev;
@@ -1390,6 +1677,7 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
     }
     CSLAM_TRY(launch_norms(p, p->n, n_rows, p->stream));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    p->dev_pending = false;  // the stream waited for it and has drained
     p->n += n_rows;
     return CSLAM_OK;
 }
@@ -1401,13 +1689,14 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
+    CSLAM_TRY(order_after_dev(p, st));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
     hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
                        row_stride, p->dim, p->rows + p->n * p->xs, p->xs, p->dp, n_rows);
     CSLAM_HIP_TRY(hipGetLastError());
     CSLAM_TRY(launch_norms(p, p->n, n_rows, st));
     p->n += n_rows;
-    return CSLAM_OK;
+    return mark_dev(p, st);
 }
 
 int64_t cslam_pool_size(const cslam_pool_t* p) { return p ? p->n : 0; }
@@ -1420,6 +1709,7 @@ int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float*
                     (long long)first, (long long)n, (long long)(p ? p->cap : 0));
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
+    if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     CSLAM_HIP_TRY(hipMemcpy2D(out, (size_t)p->dim * sizeof(float), p->rows + first * p->xs,
                               (size_t)p->xs * sizeof(float), (size_t)p->dim * sizeof(float),
@@ -1432,6 +1722,7 @@ int cslam_pool_read_inv_norms(const cslam_pool_t* p, int64_t first, int64_t n, f
         return fail(CSLAM_E_INVALID, "pool_read_inv_norms: bad range");
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
+    if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     CSLAM_HIP_TRY(hipMemcpy(out, p->inv_norm + first, (size_t)n * sizeof(float),
                             hipMemcpyDeviceToHost));
@@ -1453,8 +1744,10 @@ int cslam_pool_search_dev(cslam_pool_t* p, const float* queries_dev, int64_t que
         return fail(CSLAM_E_INVALID, "pool_search_dev: bad args");
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
-    return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev,
-                           st);
+    CSLAM_TRY(order_after_dev(p, st));
+    CSLAM_TRY(search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev,
+                              st));
+    return mark_dev(p, st);
 }
 
 int cslam_pool_search_range_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
@@ -1466,8 +1759,10 @@ int cslam_pool_search_range_dev(cslam_pool_t* p, const float* queries_dev, int64
         return fail(CSLAM_E_INVALID, "pool_search_range_dev: bad args");
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
-    return search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev, st,
-                           row_lo, row_hi);
+    CSLAM_TRY(order_after_dev(p, st));
+    CSLAM_TRY(search_dev_impl(p, queries_dev, query_stride, n_queries, k, out_idx_dev, out_sim_dev,
+                              st, row_lo, row_hi));
+    return mark_dev(p, st);
 }
 
 int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
@@ -1479,6 +1774,7 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
     if (n_queries == 0 || p->n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
+    CSLAM_TRY(order_after_dev(p, st));
     p->v0 = 0;
     p->vn = p->n;
     for (int q0 = 0; q0 < n_queries; q0 += (int)kQueryChunk) {
@@ -1490,7 +1786,7 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
                            sims_stride, p->n, p->inv_norm, p->rnq.as<float>());
         CSLAM_HIP_TRY(hipGetLastError());
     }
-    return CSLAM_OK;
+    return mark_dev(p, st);
 }
 
 int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int k,
@@ -1507,6 +1803,7 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
     CSLAM_TRY(p->h_q.reserve(qbytes));
     CSLAM_TRY(p->h_idx.reserve(obytes * sizeof(int32_t)));
     CSLAM_TRY(p->h_sim.reserve(obytes * sizeof(float)));
+    CSLAM_TRY(order_after_dev(p, p->stream));
     CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, queries, qbytes, hipMemcpyHostToDevice, p->stream));
     CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, p->h_idx.as<int32_t>(),
                               p->h_sim.as<float>(), p->stream));
@@ -1515,6 +1812,7 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
     CSLAM_HIP_TRY(hipMemcpyAsync(out_sim, p->h_sim.p, obytes * sizeof(float), hipMemcpyDeviceToHost,
                                  p->stream));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+    p->dev_pending = false;
     return CSLAM_OK;
 }
 
@@ -1531,6 +1829,8 @@ int cslam_pool_profile_begin(cslam_pool_t* p, int max_launches) {
     p->prof_on = true;
     return CSLAM_OK;
 }
+
+const char* cslam_pool_scan_kernel(const cslam_pool_t* p) { return p ? p->last_scan_kernel : ""; }
 
 int cslam_pool_profile_end(cslam_pool_t* p, double* avg_scan_ms, int* n_launches) {
     if (!p || !avg_scan_ms || !n_launches) return fail(CSLAM_E_INVALID, "profile_end: bad args");

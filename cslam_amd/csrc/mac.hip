@@ -2557,7 +2557,11 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
                            hipMemset(mac->tk_hist, 0, sizeof(unsigned int) * kTopkBins) != hipSuccess ||
                            hipMemset(mac->b, 0, sizeof(double) * n) != hipSuccess ||
                            hipEventCreate(&mac->ev0) != hipSuccess ||
-                           hipEventCreate(&mac->ev1) != hipSuccess))
+                           hipEventCreate(&mac->ev1) != hipSuccess ||
+                           // the memsets above run on the legacy null stream and are asynchronous
+                           // to the host; the solver runs on mac->stream (non-blocking, not
+                           // ordered against the null stream): finish them before any solve
+                           hipStreamSynchronize(nullptr) != hipSuccess))
         rc = fail(CSLAM_E_HIP, "mac_create: init failed");
     if (rc != CSLAM_OK) {
         cslam_mac_destroy(mac);

@@ -100,6 +100,9 @@ int cslam_pool_similarities_dev(cslam_pool_t* pool, const float* queries_dev,
  * cslam_pool_profile_begin().  */
 int cslam_pool_profile_begin(cslam_pool_t* pool, int max_launches);
 int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launches);
+/* Name (static string) of the dot-product kernel variant the last search launched, e.g.
+ * "k_scan_dma<NS=8,NW=4,NST=2,nt>": what the roofline line of bench.py is about. */
+const char* cslam_pool_scan_kernel(const cslam_pool_t* pool);
 
 /* ------------------------------------------------------------------------------------------
  * MAC problem  — cslam/mac/mac.py:19-233

@@ -192,10 +192,47 @@ def test_range_search_and_sharded_step_on_gpu(gpu):
     assert sh.matcher.size == 4
 
 
+def test_device_append_is_ordered_before_host_api(gpu):
+    """A device-pointer append on a busy caller stream followed, with NO synchronisation, by the
+    host-pointer API (own non-blocking stream): the search must see the appended rows, and a
+    host add that grows the pool must not lose them (ordering by event, csrc/knn.hip mark_dev /
+    order_after_dev)."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    rs = np.random.RandomState(21)
+    base = rs.rand(900, 512).astype(np.float32)
+    blk = rs.rand(90, 512).astype(np.float32)
+    m = NearestNeighborsMatching(dim=512)              # capacity 1000 like the reference
+    m.add_items(base, list(range(900)))
+    side = torch.cuda.Stream()
+    big = torch.rand((6144, 6144), device="cuda")
+    blk_d = torch.from_numpy(blk).cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):                            # keeps the side stream busy for a while
+            big = big @ big
+            big /= big.norm()
+        m.add_items_tensor(blk_d, list(range(900, 990)))
+    rows, sims = m.search_batch(blk[37:38], 1)         # host API, nothing synchronised
+    assert rows[0, 0] == 937 and abs(sims[0, 0] - 1.0) < 1e-6
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            big = big @ big
+            big /= big.norm()
+        m.add_items_tensor(blk_d[:5].contiguous(), list(range(990, 995)))
+    m.add_items(base[:20], list(range(995, 1015)))     # grows 1000 -> 2000 right behind it
+    got = m.data.cpu().numpy()
+    np.testing.assert_array_equal(got[990:995], blk[:5])
+    np.testing.assert_array_equal(got[995:1015], base[:20])
+    np.testing.assert_array_equal(got[900:990], blk)
+    m.close()
+
+
 def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
-    """CSLAM_SCAN_KERNEL=lds (block-synchronous LDS-staged query tiles) and =pc (producer /
-    consumer LDS ring) must give the same bits as the default register-ring kernel: all three
-    implement the one canonical order."""
+    """CSLAM_SCAN_KERNEL=lds (block-synchronous LDS-staged query tiles), =pc (producer /
+    consumer LDS ring) and =dma (X streamed through LDS-DMA, forced here on a pool far below
+    its switch-over size: 209 one-strip panels, partial strips) must give the same bits as the
+    register-ring kernel: all four implement the one canonical order."""
     import subprocess, sys, os, json
     code = (
         "import sys, json, numpy as np; sys.path.insert(0, '.');"
@@ -205,13 +242,35 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
         "m.add_items(X, list(range(3333))); r, s = m.search_batch(Q, 10);"
         "print(json.dumps([r.tolist(), s.view(np.int32).tolist()]))")
     outs = []
-    for kern in ("ring", "lds", "pc"):
+    for kern in ("ring", "lds", "pc", "dma"):
         env = dict(os.environ, CSLAM_SCAN_KERNEL=kern)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert out.returncode == 0, out.stderr
         outs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (16384, 256, 16, 10),     # exactly the switch-over size, one 256-float slice
+    (20011, 512, 5, 10),      # ragged rows: 1024 panels of 19-20 rows (partial strips everywhere)
+    (17000, 4096, 3, 1),      # cfg2 row shape
+    (40000, 768, 16, 3),      # odd number of slices: the last 512-float chunk is a half chunk
+    (140000, 256, 9, 10),     # more than 128 rows per wave: two panels per wave
+])
+def test_dma_scan_matches_oracle(gpu, n, d, m, k):
+    """k_scan_dma (the default dots kernel from 16384 rows when dim % 256 == 0) against the C
+    oracle, bit for bit, on shapes that cover its panel / strip / slice edge cases."""
+    rs = np.random.RandomState(n + d)
+    X = (rs.rand(n, d).astype(np.float32) - 0.3)
+    Q = rs.rand(m, d).astype(np.float32)
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = mt.search_batch(Q, k)
+    assert gpu.cslam_pool_scan_kernel(mt.handle).decode().startswith("k_scan_dma")
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, k)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    mt.close()
 
 
 def test_full_size_properties(gpu):
