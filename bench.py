@@ -5,32 +5,49 @@ Metric (BASELINE.json): loop-closure candidates/sec (kNN+MAC), 100k keyframes x 
 Fiedler-solve ms.
 
 Workload (configs[1], fits one GPU): every rank is one robot holding a resident pool of
-100 000 keyframe descriptors x 4096 fp32 (rows L2-normalised, seed = rank).  One step = the
-swarm publishes 16 new global descriptors (16/N per rank, already in HBM), they are
-all-gathered over RCCL when N > 1, and every rank finds the best match (k = 1, the
-`search_best` of cslam/loop_closure_sparse_matching.py:49,69) of all 16 in its pool:
-one HBM-bound scan of the pool + exact top-k.  16 candidate evaluations per rank per step →
-value = N * 16 / step time.  Per-GPU work is fixed as N grows (weak scaling); the only
-collective is the all-gather of new descriptors.
+100 000 keyframe descriptors x 4096 fp32 (rows L2-normalised, seed = rank).
 
-Extra keys: `roofline` (scan kernel, algorithmic bytes / HIP-event time on the launch stream),
-`cpu_baseline` (oracle/knn_oracle.c timed on this host, rank 0, N=1 only), `extras`
-(single-query latency, k=10, bulk 1024-query throughput, MAC Fiedler solve ms).
+  N = 1   one step = the best match (k = 1, the `search_best` of
+          cslam/loop_closure_sparse_matching.py:49,69) of 16 new descriptors, already in HBM,
+          in the pool: one HBM-bound scan + exact top-1.  value = 16 / step time.
+  N > 1   one step = the sharded protocol of SURVEY.md §8e through the C ABI
+          (cslam_amd.multi_robot.DeviceShard → csrc/shard.hip, csrc/comm.hip): every rank
+          publishes 16/N new descriptors, RCCL all-gather of the blocks, the own block is
+          appended to the pool, ONE scan of the pool for all 16 gathered descriptors (foreign ones:
+          inter-robot match, lcsm.py:58-76 / 37-56; own ones: intra-robot match, lcsm.py:78-97),
+          20-byte match records built on the device, RCCL all-gather of the records, records
+          fetched by the host.  16 best-match evaluations per rank per step, per-GPU work fixed
+          as N grows (weak scaling): value = N * 16 / step time.  The exchange of step t+1 is
+          issued before the scan of step t (different streams), records are fetched one step late.
+
+`python bench.py --gpus N` launches its own N ranks (children started before anything touches
+the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one
+of the ranks.
+
+Extra keys: `roofline` (the scan kernel: algorithmic bytes / HIP-event time on its launch
+stream), `cpu_baseline` (oracle/knn_oracle.c timed on this host; rank 0, N = 1 only), `extras`
+(host-pointer rate incl. PCIe, append+search step, single-query latency, k = 10, 32/64/1024-query
+batches, MAC Fiedler solve / Frank-Wolfe selection), `dist` (N > 1: backend, world size,
+transport, all-gather payload).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 N_KEYFRAMES = 100_000
 DIM = 4096
 BATCH = 16
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6290 measured copy)
+METRIC = "loop-closure candidates/sec (kNN+MAC), 100k keyframes x 4096-d; Fiedler-solve ms"
 
 
 def parse():
@@ -45,20 +62,53 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Start N fresh rank processes of this script and relay rank 0's JSON line.  Runs before
+    torch or the HIP runtime are imported: the parent never touches a GPU, nothing is exec'd."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} "
+                         "(launch N ranks for --gpus N, or none at all)")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     import torch
     import torch.distributed as dist
 
     from cslam_amd import _lib
     from cslam_amd.nns_matching import NearestNeighborsMatching
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     # rehearsal knobs (one-GPU boxes): CSLAM_BENCH_BACKEND=gloo exchanges through host memory,
     # CSLAM_BENCH_SAME_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
     backend = os.environ.get("CSLAM_BENCH_BACKEND", "nccl")
@@ -75,23 +125,21 @@ def main():
 
     L = _lib.load()
     N, D = args.keyframes, args.dim
+    per_rank = max(1, BATCH // world)
+    gathered_rows = per_rank * world
+    total_steps = args.warmup + args.steps
 
     # ---- resident pool (robot = rank) -------------------------------------------------------
     g = torch.Generator(device=dev).manual_seed(rank)
     X = torch.rand((N, D), device=dev, generator=g)
     X /= X.norm(dim=1, keepdim=True)
-    pool = NearestNeighborsMatching(dim=D, device_id=local_rank, capacity_hint=N)
+    grow = (total_steps + 8) * per_rank if world > 1 else 0
+    pool = NearestNeighborsMatching(dim=D, device_id=local_rank, capacity_hint=N + grow)
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(L.cslam_pool_add_dev(pool.handle, ctypes.c_void_p(X.data_ptr()), N, D,
-                                    ctypes.c_void_p(stream)))
+    pool.add_items_device(X.data_ptr(), N, D, items=None, stream=stream)
     torch.cuda.synchronize()
-    pool.n = N
-    x_host_sample = None
 
-    per_rank = max(1, BATCH // world)
-    gathered_rows = per_rank * world
     new_local = torch.rand((per_rank, D), device=dev, generator=g)
-    gathered = torch.empty((gathered_rows, D), device=dev) if world > 1 else new_local
     out_idx = torch.empty((gathered_rows, 1), dtype=torch.int32, device=dev)
     out_sim = torch.empty((gathered_rows, 1), dtype=torch.float32, device=dev)
 
@@ -101,64 +149,114 @@ def main():
                                            ctypes.c_void_p(os_.data_ptr()),
                                            ctypes.c_void_p(stream)))
 
-    # N > 1: the all-gather of step t+1's descriptors runs on RCCL's stream while the scan of
-    # step t runs on the compute stream (two landing buffers); every step still does one
-    # all-gather and one search, and both are inside the timed region.
-    landing = [gathered, torch.empty_like(gathered)] if world > 1 else [gathered]
-    pending = [None]
+    dist_info = None
+    state = {"published": 0, "matched": 0, "fetched": 0, "records": 0}
+    if world == 1:
+        def step(t):
+            search(new_local, 1, out_idx, out_sim)
 
-    def issue_gather(slot):
-        pending[0] = dist.all_gather_into_tensor(landing[slot], new_local, async_op=True)
-
-    def step(t):
-        if world > 1:
-            pending[0].wait()          # compute stream waits for the descriptors of step t
-            issue_gather((t + 1) & 1)  # step t+1's exchange overlaps this step's scan
-            search(landing[t & 1], 1, out_idx, out_sim)
+        def drain():
+            pass
+    else:
+        from cslam_amd.multi_robot import (CallbackComm, DeviceShard, RcclComm,
+                                           torch_dist_transport)
+        if backend == "nccl":
+            # two RCCL communicators (descriptor and record exchange overlap each other); their
+            # ids travel over the process group
+            ids = torch.zeros((2, _lib.CSLAM_COMM_ID_BYTES), dtype=torch.uint8, device=dev)
+            if rank == 0:
+                for i in range(2):
+                    ids[i] = torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8).to(dev)
+            dist.broadcast(ids, 0)
+            ids_h = ids.cpu().numpy()
+            comm_d = RcclComm(rank, world, ids_h[0].tobytes(), local_rank)
+            comm_r = RcclComm(rank, world, ids_h[1].tobytes(), local_rank)
         else:
-            search(gathered, 1, out_idx, out_sim)
+            name = f"{backend} through host memory (one-GPU rehearsal)"
+            comm_d = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
+            comm_r = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
+        # threshold 0: every evaluation on non-negative data yields a candidate;
+        # nb_best_matches / min_inbetween: defaults of loop_closure_detection_node.py:28-29
+        shard = DeviceShard(pool, rank, world, per_rank, 0.0, comm_d, comm_r, nb_best_matches=10,
+                            intra_min_inbetween=10)
+        blocks = torch.rand((8, per_rank, D), device=dev, generator=g)   # new keyframes, cycled
+        next_kf = [N]
+
+        def publish():
+            kfs = list(range(next_kf[0], next_kf[0] + per_rank))
+            next_kf[0] += per_rank
+            shard.publish(blocks[state["published"] % 8], kfs, stream)
+            state["published"] += 1
+
+        def step(t):
+            # exchange of step t+1 first (own stream), then step t's append + scan + records;
+            # the records of step t-1 are fetched while step t runs
+            if state["published"] == state["matched"]:
+                publish()
+            publish()
+            shard.match(stream)
+            state["matched"] += 1
+            if state["matched"] - state["fetched"] > 1:
+                state["records"] += len(shard.fetch_records())
+                state["fetched"] += 1
+
+        def drain():
+            while state["fetched"] < state["matched"]:
+                state["records"] += len(shard.fetch_records())
+                state["fetched"] += 1
 
     def fence():
         if world > 1:
-            if pending[0] is not None:
-                pending[0].wait()
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
-        issue_gather(0)
     for t in range(args.warmup):
         step(t)
+    drain()
     fence()
     _lib.check(L.cslam_pool_profile_begin(pool.handle, args.steps))
+    bytes0 = 0
     if world > 1:
-        issue_gather(0)
-        fence()
+        state["records"] = 0
+        bytes0 = comm_d.stats()["bytes_gathered"] + comm_r.stats()["bytes_gathered"]
+    fence()
     t0 = time.perf_counter()
     for t in range(args.steps):
         step(t)
-    fence()
+    drain()                       # every timed step's records are on the host
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fence()
     scan_ms = ctypes.c_double()
     n_l = ctypes.c_int()
     _lib.check(L.cslam_pool_profile_end(pool.handle, ctypes.byref(scan_ms), ctypes.byref(n_l)))
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        sd, sr = comm_d.stats(), comm_r.stats()
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "transport": comm_d.transport, "rccl_version": sd["rccl_version"],
+                     "allgather_payload_bytes_per_step":
+                         (sd["bytes_gathered"] + sr["bytes_gathered"] - bytes0) / args.steps,
+                     "collectives_per_step": 3,
+                     "match_records_per_step": state["records"] / args.steps,
+                     "new_descriptors_per_rank_per_step": per_rank}
 
     ms_per_step = dt / args.steps * 1e3
     value = world * gathered_rows / (dt / args.steps)
 
     # scan kernel roofline: algorithmic bytes of one launch:
-    #   pool rows N*D*4 + staged queries M*D*4 + results M*k*8
-    alg_bytes = N * D * 4 + gathered_rows * D * 4 + gathered_rows * 1 * 8
-    achieved = alg_bytes / (scan_ms.value * 1e-3) / 1e9 if scan_ms.value > 0 else 0.0
-    # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes
-    # (tools/pmc_traffic.sh) and summarised in profiles/r02_scan_pmc.json; it is only quoted
-    # when that summary is about the kernel variant that ran here
+    #   pool rows N*D*4 + queries M*D*4 + results M*k*8
     scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()
+    n_rows_scanned = N if world == 1 else N + (args.warmup + args.steps // 2) * per_rank
+    k_sel = 1 if world == 1 else per_rank + 10
+    alg_bytes = n_rows_scanned * D * 4 + gathered_rows * D * 4 + gathered_rows * k_sel * 8
+    achieved = alg_bytes / (scan_ms.value * 1e-3) / 1e9 if scan_ms.value > 0 else 0.0
+    # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes and
+    # summarised in profiles/r02_scan_pmc.json; it is only quoted when that summary is about
+    # the kernel variant and the shape that ran here
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r02_scan_pmc.json")
     if os.path.exists(pmc):
@@ -169,8 +267,15 @@ def main():
         except Exception:
             traffic = None
 
+    workload = ("cfg2: 100k keyframes x 4096-d fp32 pool per GPU, 16 new descriptors per step, "
+                "best match (k=1) in the pool")
+    if world > 1:
+        workload = (f"cfg2 pool per GPU under the cfg4 protocol: every rank publishes {per_rank} new "
+                    "descriptors per step, RCCL all-gather, append, one scan of the pool for all "
+                    f"{gathered_rows} gathered descriptors (inter- and intra-robot match), match "
+                    "records built on the device, RCCL all-gather of the records, fetched by the host")
     result = {
-        "metric": "loop-closure candidates/sec (kNN+MAC), 100k keyframes x 4096-d; Fiedler-solve ms",
+        "metric": METRIC,
         "value": value,
         "unit": "candidates/s",
         "n_gpus": world,
@@ -182,38 +287,44 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "cfg2: 100k keyframes x 4096-d fp32 pool per GPU, 16 new "
-                               "descriptors per step, best match (k=1) in the pool",
-                   "keyframes_per_gpu": N, "dim": D, "queries_per_step_per_gpu": gathered_rows,
-                   "k": 1, "parallelism": f"robot-per-gpu x{world}"
-                                          + (" + RCCL all-gather of new descriptors, overlapped "
-                                             "with the previous step's scan" if world > 1 else "")},
+        "config": {"workload": workload, "keyframes_per_gpu": N, "dim": D,
+                   "queries_per_step_per_gpu": gathered_rows, "k": 1,
+                   "parallelism": f"robot-per-gpu x{world}"},
         "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_of_measured_copy_peak": achieved / 6290.0,
                      "traffic": traffic, "avg_kernel_ms": scan_ms.value,
                      "launches_timed": n_l.value, "algorithmic_bytes_per_launch": alg_bytes},
     }
+    if dist_info:
+        result["dist"] = dist_info
 
     if rank == 0 and world == 1 and not args.no_extras:
-        result["extras"] = extras(torch, L, _lib, pool, dev, g, stream, N, D)
+        result["extras"] = extras(torch, L, _lib, pool, dev, g, stream, N, D, X)
         # the second half of the headline metric ("Fiedler-solve ms"), BASELINE.json configs[2]
         if "fiedler_cold_device_ms" in result["extras"]:
             result["fiedler_solve_ms"] = result["extras"]["fiedler_cold_device_ms"]
             result["select_candidates_20fw_ms"] = result["extras"]["fw_subset_20iters_ms"]
             if "acm_select_candidates_ms" in result["extras"]:   # graph assembly + MAC, end to end
                 result["acm_select_candidates_ms"] = result["extras"]["acm_select_candidates_ms"]
+        for key in ("value_incl_h2d", "value_append_then_search"):
+            if key in result["extras"]:
+                result[key] = result["extras"][key]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, X, new_local, out_idx, out_sim)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        shard.close()
+        comm_d.close()
+        comm_r.close()
         dist.destroy_process_group()
 
 
-def extras(torch, L, _lib, pool, dev, g, stream, N, D):
+def extras(torch, L, _lib, pool, dev, g, stream, N, D, X):
     """Secondary numbers of the same path (not the headline value)."""
+    import numpy as np
     out = {}
 
     def timed(q, k, reps):
@@ -237,7 +348,7 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     # MAC first: the solver is latency-bound, and the clocks sag for a while after the
     # 100-TFLOP/s bulk pass below
     try:
-        from cslam_amd.mac.bench_util import acm_select_bench, fiedler_bench
+        from mac_bench_util import acm_select_bench, fiedler_bench
         out.update(fiedler_bench())
         out.update(acm_select_bench())
     except ImportError:
@@ -245,6 +356,27 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     q1 = torch.rand((1, D), device=dev, generator=g)
     q16 = torch.rand((16, D), device=dev, generator=g)
     q1024 = torch.rand((1024, D), device=dev, generator=g)
+
+    # the same 16-descriptor step through the HOST-pointer entry point (cslam_pool_search):
+    # H2D of the queries + D2H of the results included — what a caller without device buffers
+    # pays (SURVEY §8d's "H2D included" rate; never the headline value)
+    qh = np.ascontiguousarray(q16.cpu().numpy())
+    idx_h = np.empty((16, 1), np.int32)
+    sim_h = np.empty((16, 1), np.float32)
+    cnt_h = np.empty(16, np.int32)
+
+    def host_step():
+        _lib.check(L.cslam_pool_search(pool.handle, _lib.ptr(qh), 16, 1, _lib.ptr(idx_h),
+                                       _lib.ptr(sim_h), _lib.ptr(cnt_h)))
+    for _ in range(3):
+        host_step()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        host_step()
+    th = (time.perf_counter() - t0) / 50
+    out["host_pointer_16queries_ms"] = th * 1e3
+    out["value_incl_h2d"] = 16 / th
+
     t = timed(q1, 1, 50)
     out["search_best_1query_ms"] = t * 1e3
     t = timed(q16, 10, 50)
@@ -257,6 +389,39 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D):
     out["bulk_1024queries_ms"] = t * 1e3
     out["bulk_1024queries_candidates_per_s"] = 1024 / t
     out["bulk_1024queries_tflops"] = 2.0 * N * D * 1024 / t / 1e12
+
+    # the reference's real per-keyframe sequence (lcsm.py:45-49): add_item, then search_best —
+    # here for a block of 16: append the 16 rows to a pool of the same size, then match them.
+    # Own pool with head-room so the 100k-row pool above keeps its size.
+    try:
+        from cslam_amd.nns_matching import NearestNeighborsMatching
+        reps = 40
+        p2 = NearestNeighborsMatching(dim=D, device_id=dev.index, capacity_hint=N + 16 * (reps + 4))
+        p2.add_items_device(X.data_ptr(), N, D, items=None, stream=stream)
+        blocks = torch.rand((4, 16, D), device=dev, generator=g)
+        oi = torch.empty((16, 1), dtype=torch.int32, device=dev)
+        os_ = torch.empty((16, 1), dtype=torch.float32, device=dev)
+
+        def append_search(i):
+            b = blocks[i % 4]
+            _lib.check(L.cslam_pool_add_dev(p2.handle, ctypes.c_void_p(b.data_ptr()), 16, D,
+                                            ctypes.c_void_p(stream)))
+            _lib.check(L.cslam_pool_search_dev(p2.handle, ctypes.c_void_p(b.data_ptr()), D, 16, 1,
+                                               ctypes.c_void_p(oi.data_ptr()),
+                                               ctypes.c_void_p(os_.data_ptr()), ctypes.c_void_p(stream)))
+        for i in range(3):
+            append_search(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            append_search(i)
+        torch.cuda.synchronize()
+        ta = (time.perf_counter() - t0) / reps
+        out["append16_then_search_ms"] = ta * 1e3
+        out["value_append_then_search"] = 16 / ta
+        p2.close()
+    except Exception as e:  # an extra, never fatal for the headline
+        out["append_then_search_error"] = repr(e)
     return out
 
 
@@ -274,17 +439,18 @@ def cpu_baseline(torch, X, queries, gpu_idx, gpu_sim):
     idx, sim, _ = oracle_knn.search(xs, q, 1)
     dt = time.perf_counter() - t0
     full = dt * X.shape[0] / rows
-    # while we are here: the GPU's answer for the same queries restricted to the sample
-    # cannot be compared directly (different row set); parity is the job of tests/.
     out = {"value": q.shape[0] / full, "unit": "candidates/s",
            "cores": int(oracle_knn.num_threads()), "kind": "port",
            "sample": f"{q.shape[0]} queries x {rows} of {X.shape[0]} rows x {X.shape[1]}-d, "
                      f"k=1, OpenMP over rows; {dt:.2f} s measured, scaled x{X.shape[0] / rows:.1f} "
-                     "to the full pool"}
+                     "to the full pool",
+           "note": "strict fmaf chain of the numeric contract (cannot vectorise); the reference's "
+                   "own torch-CPU search of the same pool measured 1.1 queries/s on 8 cores "
+                   "(BASELINE.md, build container)"}
     # second half of the metric: one Fiedler solve of the cfg3 graph on the CPU path the reference
     # uses (networkx TraceMIN + SuperLU, restated in oracle/mac_oracle.py; single-threaded scipy)
     try:
-        from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+        from mac_bench_util import cfg3_graph, greedy_w
         from oracle import mac_oracle
         n, fixed, cand = cfg3_graph()
         orc = mac_oracle.MacOracle([e.i for e in fixed], [e.j for e in fixed], [e.weight for e in fixed],

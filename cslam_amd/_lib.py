@@ -18,6 +18,9 @@ CSLAM_E_HIP = -2
 CSLAM_E_NODEVICE = -3
 CSLAM_E_DISCONNECTED = -4
 CSLAM_E_NOCONV = -5
+CSLAM_E_COMM = -6
+CSLAM_COMM_ID_BYTES = 128
+CSLAM_COMM_OWN_STREAM = ctypes.c_void_p(-1)
 
 
 class CslamHipError(RuntimeError):
@@ -50,6 +53,7 @@ SIGNATURES = {
     "cslam_pool_size": (_c.c_int64, [_vp]),
     "cslam_pool_capacity": (_c.c_int64, [_vp]),
     "cslam_pool_dim": (_c.c_int, [_vp]),
+    "cslam_pool_device": (_c.c_int, [_vp]),
     "cslam_pool_read_rows": (_c.c_int, [_vp, _c.c_int64, _c.c_int64, _vp]),
     "cslam_pool_read_inv_norms": (_c.c_int, [_vp, _c.c_int64, _c.c_int64, _vp]),
     "cslam_pool_device_view": (_c.c_int, [_vp, _c.POINTER(_vp), _i64p]),
@@ -61,6 +65,27 @@ SIGNATURES = {
     "cslam_pool_profile_begin": (_c.c_int, [_vp, _c.c_int]),
     "cslam_pool_profile_end": (_c.c_int, [_vp, _f64p, _c.POINTER(_c.c_int)]),
     "cslam_pool_scan_kernel": (_c.c_char_p, [_vp]),
+    "cslam_comm_unique_id": (_c.c_int, [_vp]),
+    "cslam_comm_init": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _c.POINTER(_vp)]),
+    "cslam_comm_init_custom": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.POINTER(_vp)]),
+    "cslam_device_copy": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int]),
+    "cslam_comm_destroy": (_c.c_int, [_vp]),
+    "cslam_comm_rank": (_c.c_int, [_vp]),
+    "cslam_comm_size": (_c.c_int, [_vp]),
+    "cslam_comm_stream": (_vp, [_vp]),
+    "cslam_comm_stats": (_c.c_int, [_vp, _i64p, _i64p, _i32p]),
+    "cslam_comm_allgather": (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _vp]),
+    "cslam_allgather_descriptors": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int32, _c.c_int32,
+                                               _c.c_int32, _vp, _vp, _vp]),
+    "cslam_shard_create": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
+                                      _c.c_int, _c.c_int, _c.POINTER(_vp)]),
+    "cslam_shard_destroy": (_c.c_int, [_vp]),
+    "cslam_shard_set_keyframes": (_c.c_int, [_vp, _c.c_int64, _vp, _c.c_int64]),
+    "cslam_shard_publish": (_c.c_int, [_vp, _vp, _c.c_int64, _vp, _c.c_int, _vp]),
+    "cslam_shard_match": (_c.c_int, [_vp, _vp]),
+    "cslam_shard_fetch": (_c.c_int, [_vp, _vp, _c.c_int64, _i64p, _i64p]),
+    "cslam_shard_max_records": (_c.c_int64, [_vp]),
+    "cslam_shard_pending": (_c.c_int, [_vp, _i64p, _i64p, _i64p]),
     "cslam_mac_create": (_c.c_int, [_c.c_int32, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp,
                                     _c.c_int64, _c.c_int, _c.POINTER(_vp)]),
     "cslam_mac_destroy": (_c.c_int, [_vp]),
@@ -75,6 +100,9 @@ SIGNATURES = {
     "cslam_ransac_rigid3d": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _c.c_uint64,
                                         _c.c_int, _vp, _vp, _vp, _i32p]),
 }
+
+# transport callback of cslam_comm_init_custom
+ALLGATHER_FN = _c.CFUNCTYPE(_c.c_int, _vp, _vp, _vp, _c.c_int64, _vp)
 
 _LIB = None
 

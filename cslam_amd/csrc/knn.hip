@@ -702,12 +702,23 @@ struct DmaCursor {   // position of a stage in a wave's work list
     int s;           // strip inside the panel
 };
 
-template <int NS, int NW, int NST, int AUX>
+//   BEST = true (search_best, k = 1): nothing but 16 x n_panels composites leaves the kernel.
+//   1/||q|| is accumulated from the B fragments in the oracle's wave64 order (scan lane (r, g)
+//   holds, for query r, exactly the floats of norm lanes 4i + g, i = 0..15: 16 fmaf chains per
+//   lane, then the xor butterfly 32..4 inside the lane's registers and 2, 1 across g), the
+//   epilogue applies (dot * rn(x)) * rn(q) and keeps the panel's best (similarity desc, row asc)
+//   composite per query; the queries may be read in place (q_rows = m, any stride) — no
+//   staging kernel, no dots round trip, one small select over n_panels candidates afterwards.
+template <int NS, int NW, int NST, int AUX, bool BEST>
 __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
                                                       int64_t n, int dp,
-                                                      const float* __restrict__ Q, int m_valid,
+                                                      const float* __restrict__ Q, int64_t q_stride,
+                                                      int q_rows, int m_valid,
                                                       float* __restrict__ dots,
-                                                      int64_t dots_stride, int n_panels, int ppw) {
+                                                      int64_t dots_stride, int n_panels, int ppw,
+                                                      const float* __restrict__ rnx, uint32_t row0,
+                                                      uint64_t* __restrict__ cand,
+                                                      int64_t cand_stride) {
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: uniform branches
     const int lane = threadIdx.x & 63;
@@ -750,8 +761,13 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         return cnt;
     };
 
-    const float* qrow = Q + (int64_t)r * dp + 4 * g;  // this lane's B fragment column
+    // this lane's B fragment column (rows past q_rows repeat the last query: never stored)
+    const float* qrow = Q + (int64_t)(r < q_rows ? r : q_rows - 1) * q_stride + 4 * g;
     f32x4 bc[16], bn[16];
+    float ss[16];  // BEST: sum-of-squares chains of norm lanes 4i + g of query r
+    float rnq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ss[i] = 0.f;
     DmaCursor ic;  // issue cursor: runs NST stages ahead of the consumer
     panel(ic, p_begin);
     int y[NST];  // vector-memory operations issued after the stage that sits in slot i
@@ -794,6 +810,12 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
             bump(16);
             yq = 0;
+            if (BEST && p == p_begin) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ss[i] = __builtin_fmaf(bc[i][j], bc[i][j], ss[i]);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (s < ns) {
@@ -831,7 +853,44 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             wait_vm_dyn(yq);
             tie16(bn);
         }
-        if (r < m_valid) {
+        if (BEST) {
+            if (p == p_begin) {
+                // butterfly 32, 16, 8, 4 of the norm lanes = register index xor 8, 4, 2, 1;
+                // then 2, 1 = g xor 2, 1 = lane xor 32, 16 (oracle/knn_oracle.c sumsq_wave_order)
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+                    float t2[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) t2[i] = ss[i] + ss[i ^ off];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ss[i] = t2[i];
+                }
+                float v = ss[0];
+                v = v + __shfl_xor(v, 32, kWave);
+                v = v + __shfl_xor(v, 16, kWave);
+                rnq = inv_norm_from_sumsq(__shfl(v, r, kWave));  // norm lane 0 = scan lane (r, 0)
+            }
+            uint64_t best = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    const int64_t r0 = lo + 16 * s + 4 * g;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (r0 + e < hi) {
+                            const float sim = (tot[s][e] * rnx[r0 + e]) * rnq;
+                            const uint64_t c = make_comp(sim, row0 + (uint32_t)(r0 + e));
+                            best = c > best ? c : best;
+                        }
+                    }
+                }
+            }
+            uint64_t o = __shfl_xor(best, 16, kWave);
+            best = o > best ? o : best;
+            o = __shfl_xor(best, 32, kWave);
+            best = o > best ? o : best;
+            if (g == 0 && r < m_valid) cand[(int64_t)r * cand_stride + p] = best;
+        } else if (r < m_valid) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (s < ns) {
@@ -1259,6 +1318,73 @@ void launch_scan_u(cslam_pool* p, const float* Q, int m_valid, float* dots, int6
         launch_scan_t<T, S, 1>(p, Q, m_valid, dots, dots_stride, n_waves, st);
 }
 
+// does the DMA scan apply to the current row window?  (env: CSLAM_SCAN_KERNEL=ring|lds|pc keeps
+// the older kernels, =dma forces it below its switch-over size)
+bool dma_scan_applies(const cslam_pool* p) {
+    static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
+    if (p->dp % 256 != 0 || p->vn <= 0) return false;
+    if (kern_env && strcmp(kern_env, "dma") == 0) return true;
+    if (kern_env && (strcmp(kern_env, "ring") == 0 || strcmp(kern_env, "lds") == 0 ||
+                     strcmp(kern_env, "pc") == 0))
+        return false;
+    return p->vn >= kDmaMinRows;
+}
+
+// k_scan_dma over the row window [v0, v0+vn): either raw dots (best = false) or one (similarity,
+// row) composite per query and panel (best = true, *n_panels_out candidates per query)
+int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
+                    int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride,
+                    int64_t* n_panels_out, hipStream_t st) {
+    constexpr int NS = 8, NW = 4, NST = 2;
+    const int64_t nw = (int64_t)p->cus * NW;
+    int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
+    if (ppw < 1) ppw = 1;
+    int64_t n_panels = nw * ppw;
+    const int64_t strips = (p->vn + 15) / 16;
+    if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
+    if (best && cand_stride < n_panels) return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
+    const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
+    const size_t lds = (size_t)NW * NST * kDmaStageB;
+    // pool rows are read once per search: non-temporal unless the pool could stay resident
+    // in the 256-MiB Infinity Cache between searches
+    const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
+#define CSLAM_DMA_LAUNCH(AUX, BEST)                                                               \
+    do {                                                                                          \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST>,    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds));                                         \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST>), dim3(blocks), dim3(NW * 64), lds, \
+                           st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride, q_rows, \
+                           m, dots, dots_stride, (int)n_panels, (int)ppw, p->inv_norm + p->v0,    \
+                           (uint32_t)p->v0, cand, cand_stride);                                   \
+    } while (0)
+    if (best) {
+        if (nt) {
+            CSLAM_DMA_LAUNCH(2, true);
+            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt,best>";
+        } else {
+            CSLAM_DMA_LAUNCH(0, true);
+            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,best>";
+        }
+    } else {
+        if (nt) {
+            CSLAM_DMA_LAUNCH(2, false);
+            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt>";
+        } else {
+            CSLAM_DMA_LAUNCH(0, false);
+            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2>";
+        }
+    }
+#undef CSLAM_DMA_LAUNCH
+    CSLAM_HIP_TRY(hipGetLastError());
+    *n_panels_out = n_panels;
+    return CSLAM_OK;
+}
+
 // raw dots of `m` staged queries (m <= 64) → dots[q*stride + row]
 int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t dots_stride,
                 hipStream_t st) {
@@ -1282,46 +1408,12 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         // HBM latencies; kept for A/B runs, profiles/r01_scan_lds_vs_ring.txt)
         const bool use_lds = kern_env && strcmp(kern_env, "lds") == 0;
         const bool use_pc = kern_env && strcmp(kern_env, "pc") == 0;
-        // X through LDS-DMA (k_scan_dma, 5.9-6.1 TB/s) for pools that are worth it; "ring"
-        // keeps the register-ring kernel, "dma" forces the DMA kernel wherever it is legal
-        const bool force_dma = kern_env && strcmp(kern_env, "dma") == 0;
-        const bool use_dma = p->dp % 256 == 0 && p->vn > 0 && !use_lds && !use_pc &&
-                             (force_dma || (!(kern_env && strcmp(kern_env, "ring") == 0) &&
-                                            p->vn >= kDmaMinRows));
+        // X through LDS-DMA (k_scan_dma, 6.0-6.3 TB/s) for pools that are worth it
+        const bool use_dma = dma_scan_applies(p);
         if (use_dma) {
-            constexpr int NS = 8, NW = 4, NST = 2;
-            const int64_t nw = (int64_t)p->cus * NW;
-            int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
-            if (ppw < 1) ppw = 1;
-            int64_t n_panels = nw * ppw;
-            const int64_t strips = (p->vn + 15) / 16;
-            if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
-            const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
-            const size_t lds = (size_t)NW * NST * kDmaStageB;
-            // pool rows are read once per search: non-temporal unless the pool could stay
-            // resident in the 256-MiB Infinity Cache between searches
-            const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
-#define CSLAM_DMA_LAUNCH(AUX)                                                                     \
-    do {                                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
-            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX>,          \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                              (int)lds));                                         \
-            attr_set = true;                                                                      \
-        }                                                                                         \
-        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX>), dim3(blocks), dim3(NW * 64), lds, st,  \
-                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,         \
-                           dots_stride, (int)n_panels, (int)ppw);                                 \
-    } while (0)
-            if (nt) {
-                CSLAM_DMA_LAUNCH(2);
-                p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt>";
-            } else {
-                CSLAM_DMA_LAUNCH(0);
-                p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2>";
-            }
-#undef CSLAM_DMA_LAUNCH
+            int64_t n_panels = 0;
+            CSLAM_TRY(launch_scan_dma(p, Qstage, p->dp, 16, m, dots, dots_stride, false, nullptr, 0,
+                                      &n_panels, st));
         } else if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
             p->last_scan_kernel = "k_scan_pc";
             static const int ps_env = getenv("CSLAM_SCAN_PS") ? atoi(getenv("CSLAM_SCAN_PS")) : 0;
@@ -1481,6 +1573,9 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
     return CSLAM_OK;
 }
 
+int select_from_candidates(cslam_pool* p, DevBuf* src, DevBuf* dst, int64_t n_in, int64_t in_stride,
+                           int m, int k, int32_t* out_idx, float* out_sim, hipStream_t st);
+
 int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, int k,
                    int32_t* out_idx, float* out_sim, hipStream_t st) {
     const float* rnx = p->inv_norm + p->v0;
@@ -1501,10 +1596,14 @@ int select_small_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m,
                        sims_stride, rnx, rnq, (uint32_t)p->v0, nullptr, (int64_t)0, n_in, k,
                        p->cand_a.as<uint64_t>(), cstride, nullptr, nullptr);
     CSLAM_HIP_TRY(hipGetLastError());
-    DevBuf* src = &p->cand_a;
-    DevBuf* dst = &p->cand_b;
-    n_in = cstride;
-    int64_t in_stride = cstride;
+    return select_from_candidates(p, &p->cand_a, &p->cand_b, cstride, cstride, m, k, out_idx,
+                                  out_sim, st);
+}
+
+// merge levels: candidates [m][in_stride] (n_in valid per query) → top-k
+int select_from_candidates(cslam_pool* p, DevBuf* src, DevBuf* dst, int64_t n_in, int64_t in_stride,
+                           int m, int k, int32_t* out_idx, float* out_sim, hipStream_t st) {
+    int64_t parts;
     while (true) {
         parts = (n_in + kSelectPart - 1) / kSelectPart;
         if (parts <= 1) {
@@ -1563,6 +1662,41 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
                            total, out_idx, out_sim);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
+    }
+    if (k == 1 && m <= 16 && dma_scan_applies(p)) {
+        // search_best (lcsm.py:49,69): one scan launch that leaves one composite per query and
+        // row panel + one small select.  Queries are read in place when they need no padding.
+        const bool direct = p->dim == p->dp && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 &&
+                            (q_stride & 3) == 0;
+        const float* qsrc = q_dev;
+        int64_t qs = q_stride;
+        int q_rows = m;
+        if (!direct) {
+            CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+            CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+            const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+            hipLaunchKernelGGL(k_stage_queries, dim3(16, 1), dim3(256), 0, st, q_dev, q_stride,
+                               p->dim, m, 16, p->dp, p->qstage.as<float>(), p->rnq.as<float>(),
+                               vec_ok, (int64_t)0);
+            CSLAM_HIP_TRY(hipGetLastError());
+            qsrc = p->qstage.as<float>();
+            qs = p->dp;
+            q_rows = 16;
+        }
+        const int64_t cstride = ((int64_t)p->cus * 4 * ((p->vn + (int64_t)p->cus * 4 * 128 - 1) /
+                                                        ((int64_t)p->cus * 4 * 128)) + 63) / 64 * 64;
+        CSLAM_TRY(p->cand_a.reserve((size_t)16 * cstride * sizeof(uint64_t)));
+        bool prof = p->prof_on && p->prof_n < p->prof_max;
+        if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+        int64_t n_panels = 0;
+        CSLAM_TRY(launch_scan_dma(p, qsrc, qs, q_rows, m, nullptr, 0, true,
+                                  p->cand_a.as<uint64_t>(), cstride, &n_panels, st));
+        if (prof) {
+            CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
+            p->prof_n++;
+        }
+        return select_from_candidates(p, &p->cand_a, &p->cand_b, n_panels, cstride, m, 1, out_idx,
+                                      out_sim, st);
     }
     int64_t sims_stride = (p->vn + 63) / 64 * 64;
     int64_t chunk = m < kQueryChunk ? m : kQueryChunk;
@@ -1702,6 +1836,7 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
 int64_t cslam_pool_size(const cslam_pool_t* p) { return p ? p->n : 0; }
 int64_t cslam_pool_capacity(const cslam_pool_t* p) { return p ? p->cap : 0; }
 int cslam_pool_dim(const cslam_pool_t* p) { return p ? p->dim : 0; }
+int cslam_pool_device(const cslam_pool_t* p) { return p ? p->device : 0; }
 
 int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float* out) {
     if (!p || first < 0 || n < 0 || first + n > p->cap || (!out && n > 0))

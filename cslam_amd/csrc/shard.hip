@@ -1,0 +1,474 @@
+// shard.hip — rank-local half of the multi-robot matching step, entirely on the device.
+//
+// rank r = robot r holds ONLY its own descriptor pool (the reference mirrors every peer pool on
+// every robot, cslam/loop_closure_sparse_matching.py:26-32).  One swarm step:
+//   publish  own new block [b][dim] + keyframe ids  → RCCL all-gather (descriptor communicator)
+//   match    append the own block, ONE scan of the pool for all gathered descriptors,
+//            records on the device:
+//              foreign descriptor x best OLD row  → add_other_robot_global_descriptor (lcsm.py:58-76)
+//              foreign descriptor x best NEW row  → the peer's add_local_global_descriptor
+//                                                  (lcsm.py:37-56), emitted on its behalf
+//              own descriptor x local pool        → match_local_loop_closures (lcsm.py:78-97)
+//            → RCCL all-gather of the 20-byte records (record communicator) → pinned host copy
+//   fetch    the host reads the records of a finished step (rank order, slot order: every rank
+//            applies them to its selector replica in the same order)
+// Nothing in publish/match synchronises the host; steps are pipelined over kSlots buffers.
+//
+// Equivalence with the reference's sequential processing: "everybody receives the step's
+// descriptors, then everybody inserts its own" — tests/test_multi_robot.py replays that order
+// through the reference semantics and compares the union of candidate edges.
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace cslam;
+
+namespace {
+
+constexpr int kSlots = 4;        // steps in flight
+constexpr int kFusedMaxK = 64;   // b_max + k_local up to here: one scan, one top-K per descriptor
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_block(const float* __restrict__ src, int64_t src_stride,
+                                                    int b, int b_max, int dim,
+                                                    float* __restrict__ dst) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= b_max) return;
+    float* d = dst + w * dim;
+    if (w < b) {
+        const float* s = src + w * src_stride;
+        for (int k = lane; k < dim; k += 64) d[k] = s[k];
+    } else {
+        for (int k = lane; k < dim; k += 64) d[k] = 0.f;
+    }
+}
+
+// keyframe id of the pool rows appended by this step
+__global__ void k_set_kf(int32_t* __restrict__ kf_of_row, int64_t n0, const int64_t* __restrict__ meta,
+                         int b) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b) kf_of_row[n0 + i] = (int32_t)meta[1 + i];
+}
+
+// One thread per gathered descriptor i = s * b_max + j (owner s, position j).
+// FUSED: topk_idx/topk_sim hold the sorted top-K of the pool AFTER the own block was appended;
+//        the best old row (< n0) and the best new row (>= n0) are both inside it (K > b).
+// else : idx_a/sim_a = best in [0, n0), idx_c/sim_c = best in [n0, n0 + b).
+// Record slots 3i (received descriptor vs old rows), 3i+1 (vs new rows, on the peer's behalf),
+// 3i+2 (own descriptor: intra-robot match); robot0_id = -1 marks an empty slot.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_make_records(
+    int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
+    const int32_t* __restrict__ kf_of_row, double thr, const int32_t* __restrict__ topk_idx,
+    const float* __restrict__ topk_sim, int K, int k_local, int min_inbetween,
+    const int32_t* __restrict__ idx_a, const float* __restrict__ sim_a,
+    const int32_t* __restrict__ idx_c, const float* __restrict__ sim_c,
+    cslam_match_record_t* __restrict__ recs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb_robots * b_max) return;
+    const int s = i / b_max, j = i % b_max;
+    const int64_t* meta = all_meta + (int64_t)s * (1 + b_max);
+    cslam_match_record_t none;
+    none.robot0_id = -1;
+    none.robot0_keyframe_id = 0;
+    none.robot1_id = 0;
+    none.robot1_keyframe_id = 0;
+    none.weight = 0.f;
+    cslam_match_record_t r0 = none, r1 = none, r2 = none;
+    if (j < (int)meta[0]) {
+        const int32_t kf_s = (int32_t)meta[1 + j];
+        if (s != me) {
+            int32_t ia = -1, ic = -1;
+            float sa = 0.f, sc = 0.f;
+            if (FUSED) {
+                for (int t = 0; t < K; ++t) {
+                    const int32_t row = topk_idx[(int64_t)i * K + t];
+                    if (row < 0) break;
+                    if (row < n0) {
+                        if (ia < 0) { ia = row; sa = topk_sim[(int64_t)i * K + t]; }
+                    } else if (ic < 0) {
+                        ic = row; sc = topk_sim[(int64_t)i * K + t];
+                    }
+                    if (ia >= 0 && ic >= 0) break;
+                }
+            } else {
+                ia = idx_a[i]; sa = sim_a[i];
+                ic = idx_c[i]; sc = sim_c[i];
+            }
+            const bool a_ok = ia >= 0 && (double)sa >= thr;
+            if (a_ok) {  // this robot's add_other_robot_global_descriptor (lcsm.py:69-75)
+                r0.robot0_id = me;
+                r0.robot0_keyframe_id = kf_of_row[ia];
+                r0.robot1_id = s;
+                r0.robot1_keyframe_id = kf_s;
+                r0.weight = sa;
+            }
+            // the peer's add_local_global_descriptor would have met this newer keyframe in its
+            // mirror of our pool (lcsm.py:47-55): only when it beats every older row
+            if (ic >= 0 && (double)sc >= thr && !(ia >= 0 && sa >= sc)) {
+                r1.robot0_id = s;
+                r1.robot0_keyframe_id = kf_s;
+                r1.robot1_id = me;
+                r1.robot1_keyframe_id = kf_of_row[ic];
+                r1.weight = sc;
+            }
+        } else if (FUSED && k_local > 0) {
+            // match_local_loop_closures (lcsm.py:78-97) for own keyframe j, whose pool row is
+            // n0 + j: the reference searched the pool as it was right after inserting it, i.e.
+            // rows <= n0 + j; keep the first k_local of those, drop the keyframe itself when it
+            // ranks first, then take the first far-enough, similar-enough one
+            const int64_t self_row = n0 + j;
+            int kept = 0;
+            for (int t = 0; t < K && kept < k_local; ++t) {
+                const int32_t row = topk_idx[(int64_t)i * K + t];
+                if (row < 0) break;
+                if (row > self_row) continue;  // a later keyframe of this block: not there yet
+                ++kept;
+                if (kept == 1 && row == self_row) continue;  // lcsm.py:83-84
+                const int32_t kf = kf_of_row[row];
+                const int d = kf > kf_s ? kf - kf_s : kf_s - kf;
+                if (d < min_inbetween) continue;
+                const float sv = topk_sim[(int64_t)i * K + t];
+                if ((double)sv < thr) continue;
+                r2.robot0_id = me;
+                r2.robot0_keyframe_id = kf_s;
+                r2.robot1_id = me;
+                r2.robot1_keyframe_id = kf;
+                r2.weight = sv;
+                break;
+            }
+        }
+    }
+    recs[3 * (int64_t)i + 0] = r0;
+    recs[3 * (int64_t)i + 1] = r1;
+    recs[3 * (int64_t)i + 2] = r2;
+}
+
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct Slot {
+    float* all_rows = nullptr;        // [R][b_max][dim]   (own block at index me: in-place gather)
+    int64_t* all_meta = nullptr;      // [R][1 + b_max]    count, keyframe ids
+    int64_t* meta_host = nullptr;     // pinned [1 + b_max]
+    int32_t* topk_idx = nullptr;      // [R*b_max][K]
+    float* topk_sim = nullptr;
+    int32_t *idx_a = nullptr, *idx_c = nullptr;   // bulk mode
+    float *sim_a = nullptr, *sim_c = nullptr;
+    cslam_match_record_t* recs_all = nullptr;     // [R][3*R*b_max]  (own part at index me)
+    cslam_match_record_t* recs_host = nullptr;    // pinned copy
+    hipEvent_t ev_src = nullptr, ev_pub = nullptr, ev_match = nullptr, ev_done = nullptr;
+    int b = 0;
+    int64_t step = -1;
+    int state = 0;  // 0 free, 1 published, 2 matched
+};
+
+}  // namespace
+
+struct cslam_shard {
+    cslam_pool_t* pool = nullptr;
+    cslam_comm_t* comm_desc = nullptr;
+    cslam_comm_t* comm_rec = nullptr;
+    int me = 0, R = 1, b_max = 0, dim = 0, device = 0;
+    int k_local = 0, min_inbetween = 0, K = 1;
+    bool fused = true;
+    double thr = 0.0;
+    int32_t* kf_of_row = nullptr;
+    int64_t kf_cap = 0;
+    hipStream_t s_own = nullptr;  // used when there is no communicator (single robot)
+    Slot slot[kSlots];
+    int64_t pub_step = 0, match_step = 0, fetch_step = 0;
+    int64_t rec_slots = 0;        // 3 * R * b_max
+};
+
+namespace {
+
+template <class T>
+int dalloc(T** p, size_t n) {
+    CSLAM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+    return CSLAM_OK;
+}
+
+int ensure_kf_capacity(cslam_shard* sh, int64_t want, hipStream_t st) {
+    if (want <= sh->kf_cap) return CSLAM_OK;
+    int64_t ncap = sh->kf_cap > 0 ? sh->kf_cap : 1024;
+    while (ncap < want) ncap *= 2;
+    int32_t* nk = nullptr;
+    CSLAM_TRY(dalloc(&nk, (size_t)ncap));
+    CSLAM_HIP_TRY(hipMemsetAsync(nk + sh->kf_cap, 0xFF, (size_t)(ncap - sh->kf_cap) * sizeof(int32_t), st));
+    if (sh->kf_of_row) {
+        CSLAM_HIP_TRY(hipMemcpyAsync(nk, sh->kf_of_row, (size_t)sh->kf_cap * sizeof(int32_t),
+                                     hipMemcpyDeviceToDevice, st));
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        CSLAM_HIP_TRY(hipFree(sh->kf_of_row));
+    } else {
+        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    }
+    sh->kf_of_row = nk;
+    sh->kf_cap = ncap;
+    return CSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t* comm_rec,
+                       int robot_id, int nb_robots, int max_block, double similarity_threshold,
+                       int nb_best_matches, int intra_min_inbetween, cslam_shard_t** out) {
+    if (!pool || !out || nb_robots < 1 || robot_id < 0 || robot_id >= nb_robots || max_block < 1 ||
+        nb_best_matches < 0)
+        return fail(CSLAM_E_INVALID, "shard_create: bad args");
+    if (nb_robots > 1 && (!comm_desc || !comm_rec))
+        return fail(CSLAM_E_INVALID, "shard_create: %d robots need both communicators", nb_robots);
+    if (comm_desc && (cslam_comm_size(comm_desc) != nb_robots || cslam_comm_rank(comm_desc) != robot_id))
+        return fail(CSLAM_E_INVALID, "shard_create: communicator rank/size != robot id/count");
+    if (comm_rec && (cslam_comm_size(comm_rec) != nb_robots || cslam_comm_rank(comm_rec) != robot_id))
+        return fail(CSLAM_E_INVALID, "shard_create: record communicator rank/size mismatch");
+    if (comm_desc && comm_desc == comm_rec)
+        return fail(CSLAM_E_INVALID, "shard_create: the two exchanges overlap and need two communicators");
+    cslam_shard* sh = new cslam_shard();
+    sh->pool = pool;
+    sh->comm_desc = comm_desc;
+    sh->comm_rec = comm_rec;
+    sh->me = robot_id;
+    sh->R = nb_robots;
+    sh->b_max = max_block;
+    sh->dim = cslam_pool_dim(pool);
+    sh->device = cslam_pool_device(pool);
+    sh->thr = similarity_threshold;
+    sh->fused = max_block + (nb_best_matches > 1 ? nb_best_matches : 1) <= kFusedMaxK;
+    sh->k_local = sh->fused ? nb_best_matches : 0;   // bulk blocks: inter-robot matching only
+    sh->min_inbetween = intra_min_inbetween;
+    sh->K = max_block + (sh->k_local > 1 ? sh->k_local : 1);
+    sh->rec_slots = 3 * (int64_t)nb_robots * max_block;
+    int rc = CSLAM_OK;
+    hipError_t e = hipSetDevice(sh->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh->s_own, hipStreamNonBlocking);
+    if (e != hipSuccess) rc = fail(CSLAM_E_HIP, "shard_create: %s", hipGetErrorString(e));
+    const size_t M = (size_t)nb_robots * max_block;
+    for (int i = 0; i < kSlots && rc == CSLAM_OK; ++i) {
+        Slot& s = sh->slot[i];
+        auto A = [&](int r) { if (rc == CSLAM_OK) rc = r; };
+        A(dalloc(&s.all_rows, M * sh->dim));
+        A(dalloc(&s.all_meta, (size_t)nb_robots * (1 + max_block)));
+        A(dalloc(&s.recs_all, (size_t)nb_robots * sh->rec_slots));
+        if (sh->fused) {
+            A(dalloc(&s.topk_idx, M * sh->K));
+            A(dalloc(&s.topk_sim, M * sh->K));
+        } else {
+            A(dalloc(&s.idx_a, M));
+            A(dalloc(&s.idx_c, M));
+            A(dalloc(&s.sim_a, M));
+            A(dalloc(&s.sim_c, M));
+        }
+        if (rc != CSLAM_OK) break;
+        hipError_t h = hipHostMalloc(reinterpret_cast<void**>(&s.meta_host),
+                                     (size_t)(1 + max_block) * sizeof(int64_t), hipHostMallocDefault);
+        if (h == hipSuccess)
+            h = hipHostMalloc(reinterpret_cast<void**>(&s.recs_host),
+                              (size_t)nb_robots * sh->rec_slots * sizeof(cslam_match_record_t),
+                              hipHostMallocDefault);
+        for (hipEvent_t* ev : {&s.ev_src, &s.ev_pub, &s.ev_match, &s.ev_done})
+            if (h == hipSuccess) h = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (h != hipSuccess) rc = fail(CSLAM_E_HIP, "shard_create: %s", hipGetErrorString(h));
+    }
+    if (rc == CSLAM_OK) rc = ensure_kf_capacity(sh, cslam_pool_capacity(pool), sh->s_own);
+    if (rc != CSLAM_OK) {
+        cslam_shard_destroy(sh);
+        return rc;
+    }
+    *out = sh;
+    return CSLAM_OK;
+}
+
+int cslam_shard_destroy(cslam_shard_t* sh) {
+    if (!sh) return CSLAM_OK;
+    (void)hipSetDevice(sh->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < kSlots; ++i) {
+        Slot& s = sh->slot[i];
+        for (void* p : {(void*)s.all_rows, (void*)s.all_meta, (void*)s.topk_idx, (void*)s.topk_sim,
+                        (void*)s.idx_a, (void*)s.idx_c, (void*)s.sim_a, (void*)s.sim_c,
+                        (void*)s.recs_all})
+            if (p) (void)hipFree(p);
+        if (s.meta_host) (void)hipHostFree(s.meta_host);
+        if (s.recs_host) (void)hipHostFree(s.recs_host);
+        for (hipEvent_t ev : {s.ev_src, s.ev_pub, s.ev_match, s.ev_done})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    if (sh->kf_of_row) (void)hipFree(sh->kf_of_row);
+    if (sh->s_own) (void)hipStreamDestroy(sh->s_own);
+    delete sh;
+    return CSLAM_OK;
+}
+
+/* Register rows that were put into the pool before the shard existed (or behind its back):
+ * keyframe ids of pool rows [first, first + n). */
+int cslam_shard_set_keyframes(cslam_shard_t* sh, int64_t first, const int32_t* keyframe_ids,
+                              int64_t n) {
+    if (!sh || first < 0 || n < 0 || (n > 0 && !keyframe_ids))
+        return fail(CSLAM_E_INVALID, "shard_set_keyframes: bad args");
+    if (n == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(sh->device));
+    CSLAM_TRY(ensure_kf_capacity(sh, first + n, sh->s_own));
+    CSLAM_HIP_TRY(hipMemcpy(sh->kf_of_row + first, keyframe_ids, (size_t)n * sizeof(int32_t),
+                            hipMemcpyHostToDevice));
+    return CSLAM_OK;
+}
+
+int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t row_stride,
+                        const int64_t* keyframe_ids, int b, void* stream) {
+    if (!sh || b < 0 || b > (sh ? sh->b_max : 0) || (b > 0 && (!new_rows_dev || !keyframe_ids || row_stride < sh->dim)))
+        return fail(CSLAM_E_INVALID, "shard_publish: bad args (block of %d, max %d)", b,
+                    sh ? sh->b_max : 0);
+    Slot& s = sh->slot[sh->pub_step % kSlots];
+    if (s.state != 0)
+        return fail(CSLAM_E_INVALID, "shard_publish: %d steps in flight — fetch the oldest first", kSlots);
+    CSLAM_HIP_TRY(hipSetDevice(sh->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int R = sh->R, me = sh->me, bm = sh->b_max, dim = sh->dim;
+    s.meta_host[0] = b;
+    for (int i = 0; i < bm; ++i) s.meta_host[1 + i] = i < b ? keyframe_ids[i] : -1;
+    int64_t* my_meta = s.all_meta + (int64_t)me * (1 + bm);
+    float* my_rows = s.all_rows + (int64_t)me * bm * dim;
+    CSLAM_HIP_TRY(hipMemcpyAsync(my_meta, s.meta_host, (size_t)(1 + bm) * sizeof(int64_t),
+                                 hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pack_block, dim3((unsigned)((bm + 3) / 4)), dim3(256), 0, st, new_rows_dev,
+                       row_stride, b, bm, dim, my_rows);
+    CSLAM_HIP_TRY(hipGetLastError());
+    if (R > 1) {
+        // exchange on the descriptor communicator's own stream: overlaps whatever the caller's
+        // stream does next (the previous step's scan)
+        hipStream_t cs = (hipStream_t)cslam_comm_stream(sh->comm_desc);
+        CSLAM_HIP_TRY(hipEventRecord(s.ev_src, st));
+        CSLAM_HIP_TRY(hipStreamWaitEvent(cs, s.ev_src, 0));
+        CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_rows, s.all_rows,
+                                       (int64_t)bm * dim * sizeof(float), CSLAM_COMM_OWN_STREAM));
+        CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_meta, s.all_meta,
+                                       (int64_t)(1 + bm) * sizeof(int64_t), CSLAM_COMM_OWN_STREAM));
+        CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, cs));
+    } else {
+        CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, st));
+    }
+    s.b = b;
+    s.step = sh->pub_step++;
+    s.state = 1;
+    return CSLAM_OK;
+}
+
+int cslam_shard_match(cslam_shard_t* sh, void* stream) {
+    if (!sh) return fail(CSLAM_E_INVALID, "shard_match: null");
+    if (sh->match_step >= sh->pub_step) return fail(CSLAM_E_INVALID, "shard_match: nothing published");
+    Slot& s = sh->slot[sh->match_step % kSlots];
+    if (s.state != 1) return fail(CSLAM_E_INVALID, "shard_match: slot not in published state");
+    CSLAM_HIP_TRY(hipSetDevice(sh->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int R = sh->R, me = sh->me, bm = sh->b_max, dim = sh->dim;
+    const int M = R * bm;
+    CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
+    const int64_t n0 = cslam_pool_size(sh->pool);
+    const float* my_rows = s.all_rows + (int64_t)me * bm * dim;
+    const int64_t* my_meta = s.all_meta + (int64_t)me * (1 + bm);
+    cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
+    const unsigned gm = (unsigned)((M + 255) / 256);
+    if (sh->fused) {
+        // append first, then ONE scan: the sorted top-K (K > b) of every gathered descriptor
+        // holds both its best older row and its best row of the new block
+        if (s.b > 0) {
+            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
+            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
+            hipLaunchKernelGGL(k_set_kf, dim3((unsigned)((s.b + 255) / 256)), dim3(256), 0, st,
+                               sh->kf_of_row, n0, my_meta, s.b);
+        }
+        CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows, dim, M, sh->K, s.topk_idx, s.topk_sim, st));
+        hipLaunchKernelGGL((k_make_records<true>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
+                           n0, sh->kf_of_row, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
+                           sh->min_inbetween, nullptr, nullptr, nullptr, nullptr, my_recs);
+    } else {
+        // bulk blocks: best old row of every FOREIGN descriptor (the own block is skipped: two
+        // calls around it), append, best new row through the row-range search
+        hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_a, (int64_t)M, -1);
+        hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_c, (int64_t)M, -1);
+        const int lo_n = me * bm, hi_first = (me + 1) * bm, hi_n = M - hi_first;
+        if (lo_n > 0)
+            CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows, dim, lo_n, 1, s.idx_a, s.sim_a, st));
+        if (hi_n > 0)
+            CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows + (int64_t)hi_first * dim, dim, hi_n,
+                                            1, s.idx_a + hi_first, s.sim_a + hi_first, st));
+        if (s.b > 0) {
+            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
+            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
+            hipLaunchKernelGGL(k_set_kf, dim3((unsigned)((s.b + 255) / 256)), dim3(256), 0, st,
+                               sh->kf_of_row, n0, my_meta, s.b);
+            if (lo_n > 0)
+                CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, lo_n, 1, n0,
+                                                      n0 + s.b, s.idx_c, s.sim_c, st));
+            if (hi_n > 0)
+                CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows + (int64_t)hi_first * dim,
+                                                      dim, hi_n, 1, n0, n0 + s.b, s.idx_c + hi_first,
+                                                      s.sim_c + hi_first, st));
+        }
+        hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
+                           n0, sh->kf_of_row, sh->thr, nullptr, nullptr, 1, 0, 0, s.idx_a, s.sim_a,
+                           s.idx_c, s.sim_c, my_recs);
+    }
+    CSLAM_HIP_TRY(hipGetLastError());
+    // record exchange + host copy on the record communicator's stream: off the critical path of
+    // the next step's scan
+    const size_t rec_bytes = (size_t)sh->rec_slots * sizeof(cslam_match_record_t);
+    hipStream_t rs = R > 1 ? (hipStream_t)cslam_comm_stream(sh->comm_rec) : sh->s_own;
+    CSLAM_HIP_TRY(hipEventRecord(s.ev_match, st));
+    CSLAM_HIP_TRY(hipStreamWaitEvent(rs, s.ev_match, 0));
+    if (R > 1)
+        CSLAM_TRY(cslam_comm_allgather(sh->comm_rec, my_recs, s.recs_all, (int64_t)rec_bytes,
+                                       CSLAM_COMM_OWN_STREAM));
+    CSLAM_HIP_TRY(hipMemcpyAsync(s.recs_host, s.recs_all, rec_bytes * R, hipMemcpyDeviceToHost, rs));
+    CSLAM_HIP_TRY(hipEventRecord(s.ev_done, rs));
+    s.state = 2;
+    sh->match_step++;
+    return CSLAM_OK;
+}
+
+int cslam_shard_fetch(cslam_shard_t* sh, cslam_match_record_t* out, int64_t cap, int64_t* n_out,
+                      int64_t* step_index) {
+    if (!sh || !n_out || cap < 0 || (cap > 0 && !out)) return fail(CSLAM_E_INVALID, "shard_fetch: bad args");
+    if (sh->fetch_step >= sh->match_step) return fail(CSLAM_E_INVALID, "shard_fetch: no matched step pending");
+    Slot& s = sh->slot[sh->fetch_step % kSlots];
+    CSLAM_HIP_TRY(hipSetDevice(sh->device));
+    CSLAM_HIP_TRY(hipEventSynchronize(s.ev_done));
+    int64_t n = 0;
+    const int64_t total = (int64_t)sh->R * sh->rec_slots;
+    for (int64_t i = 0; i < total; ++i) {
+        if (s.recs_host[i].robot0_id < 0) continue;
+        if (n < cap) out[n] = s.recs_host[i];
+        ++n;
+    }
+    if (n > cap) return fail(CSLAM_E_INVALID, "shard_fetch: %lld records, room for %lld", (long long)n, (long long)cap);
+    *n_out = n;
+    if (step_index) *step_index = s.step;
+    s.state = 0;
+    sh->fetch_step++;
+    return CSLAM_OK;
+}
+
+int64_t cslam_shard_max_records(const cslam_shard_t* sh) {
+    return sh ? (int64_t)sh->R * sh->rec_slots : 0;
+}
+
+int cslam_shard_pending(const cslam_shard_t* sh, int64_t* published, int64_t* matched,
+                        int64_t* fetched) {
+    if (!sh) return fail(CSLAM_E_INVALID, "shard_pending: null");
+    if (published) *published = sh->pub_step;
+    if (matched) *matched = sh->match_step;
+    if (fetched) *fetched = sh->fetch_step;
+    return CSLAM_OK;
+}
+
+}  // extern "C"

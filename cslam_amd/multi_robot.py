@@ -7,6 +7,14 @@ The ROS fan-out of `GlobalDescriptors` messages (global_descriptor_loop_closure_
 `InterRobotMatches` exchange (gdlcd.py:223-283) becomes a second, tiny all-gather of 20-byte
 match records.  There is no other collective: the scan itself never leaves the GPU.
 
+Two implementations of the same protocol live here:
+  * `DeviceShard` — the product path: the whole step is enqueued on the GPU through the C ABI
+    (`cslam_shard_*`, csrc/shard.hip), the collectives are RCCL calls made inside the library
+    (`cslam_comm_*`, csrc/comm.hip); the host only publishes blocks and fetches 20-byte records.
+  * `ShardedLoopClosureMatching` — the protocol written out on the host with a pluggable matcher
+    and `torch.distributed` collectives: what the CPU tests (gloo, world 2/3) run with the oracle
+    as the matcher, and the yardstick the device path is compared with on the GPU.
+
 Step protocol (equivalent to the reference replayed in the order "everybody receives the
 step's descriptors, then everybody inserts its own" — tests/test_multi_robot.py proves the
 union of candidate edges is identical):
@@ -209,3 +217,242 @@ class ShardedLoopClosureMatching(object):
         if is_neighbor_in_range is None:
             is_neighbor_in_range = {r: True for r in range(self.nb_robots)}
         return self.candidate_selector.select_candidates(int(budget), dict(is_neighbor_in_range))
+
+
+# ------------------------------------------------------------------------------------------------
+# Product path: communicators and the device-side step behind the C ABI
+# ------------------------------------------------------------------------------------------------
+RECORD_DTYPE = np.dtype([("robot0_id", np.int32), ("robot0_keyframe_id", np.int32),
+                         ("robot1_id", np.int32), ("robot1_keyframe_id", np.int32),
+                         ("weight", np.float32)])   # cslam_match_record_t, 20 bytes
+
+
+class RcclComm(object):
+    """cslam_comm_t over RCCL (xGMI between the GPUs of a node).  Rank 0 calls `unique_id()` and
+    hands the 128 bytes to the other ranks out of band (bench.py: torch.distributed store)."""
+
+    def __init__(self, rank, nranks, unique_id, device_id):
+        from . import _lib
+        self._lib = _lib
+        self._L = _lib.load()
+        if len(unique_id) != _lib.CSLAM_COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.CSLAM_COMM_ID_BYTES)
+        self._id = (ctypes.c_uint8 * _lib.CSLAM_COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        h = ctypes.c_void_p()
+        _lib.check(self._L.cslam_comm_init(int(rank), int(nranks), self._id, int(device_id),
+                                           ctypes.byref(h)))
+        self.handle = h
+        self.rank, self.world = int(rank), int(nranks)
+        self.transport = "rccl"
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = (ctypes.c_uint8 * _lib.CSLAM_COMM_ID_BYTES)()
+        _lib.check(_lib.load().cslam_comm_unique_id(buf))
+        return bytes(buf)
+
+    def stats(self):
+        b, n, v = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        self._lib.check(self._L.cslam_comm_stats(self.handle, ctypes.byref(b), ctypes.byref(n),
+                                                 ctypes.byref(v)))
+        return {"bytes_gathered": b.value, "collectives": n.value, "rccl_version": v.value}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.cslam_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CallbackComm(RcclComm):
+    """cslam_comm_t over a transport written in Python: `transport(send_ptr, recv_ptr,
+    bytes_per_rank, stream)` must leave every rank's bytes in `recv_ptr` (device memory)."""
+
+    def __init__(self, rank, nranks, device_id, transport, name="callback"):
+        from . import _lib
+        self._lib = _lib
+        self._L = _lib.load()
+
+        def _cb(user, send, recv, nbytes, stream):
+            try:
+                transport(send, recv, int(nbytes), stream)
+                return 0
+            except Exception as e:  # surfaces as CSLAM_E_COMM in the caller
+                self.last_exception = e
+                return 1
+
+        self._cb = _lib.ALLGATHER_FN(_cb)   # keep the thunk alive as long as the communicator
+        self.last_exception = None
+        h = ctypes.c_void_p()
+        _lib.check(self._L.cslam_comm_init_custom(int(rank), int(nranks), int(device_id), self._cb,
+                                                  None, ctypes.byref(h)))
+        self.handle = h
+        self.rank, self.world = int(rank), int(nranks)
+        self.transport = name
+
+
+class LocalGroup(object):
+    """Transport between robot shards that are THREADS of one process sharing one GPU (tests,
+    or several small robots per GPU): device-to-device copies around a thread barrier."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.send = [None] * world
+
+    def transport(self, rank):
+        from . import _lib
+        L = _lib.load()
+
+        def fn(send, recv, nbytes, stream):
+            _lib.check(L.cslam_device_copy(None, None, 0, 2, stream, 1))   # producer work done
+            self.send[rank] = send
+            self.barrier.wait()
+            for r in range(self.world):
+                if self.send[r] != recv + r * nbytes:                       # in-place own block
+                    _lib.check(L.cslam_device_copy(recv + r * nbytes, self.send[r], nbytes, 2,
+                                                   stream, 0))
+            _lib.check(L.cslam_device_copy(None, None, 0, 2, stream, 1))
+            self.barrier.wait()                                             # send buffers free again
+        return fn
+
+
+def torch_dist_transport(group=None):
+    """Transport through host memory and torch.distributed (gloo): bench.py's rehearsal of
+    `--gpus N` on a one-GPU box, where RCCL cannot place two ranks on one device."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    L = _lib.load()
+    world = dist.get_world_size(group)
+
+    def fn(send, recv, nbytes, stream):
+        mine = torch.empty(nbytes, dtype=torch.uint8)
+        _lib.check(L.cslam_device_copy(mine.data_ptr(), send, nbytes, 1, stream, 1))
+        everybody = torch.empty(world * nbytes, dtype=torch.uint8)
+        dist.all_gather_into_tensor(everybody, mine, group=group)
+        _lib.check(L.cslam_device_copy(recv, everybody.data_ptr(), world * nbytes, 0, stream, 1))
+    return fn
+
+
+class DeviceShard(object):
+    """Rank-local half of the sharded matching step on the device (csrc/shard.hip).
+
+    publish(block, keyframe_ids) → match() → fetch_records(); `step()` does all three.  Several
+    steps may be in flight (publish t+1 before match t: the exchange overlaps the scan)."""
+
+    def __init__(self, pool, robot_id, nb_robots, max_block, similarity_threshold,
+                 comm_desc=None, comm_rec=None, nb_best_matches=0, intra_min_inbetween=0,
+                 selector=None):
+        """
+        Args:
+            pool: NearestNeighborsMatching (device pool of THIS robot; dim fixed)
+            comm_desc, comm_rec: RcclComm/CallbackComm for the descriptor and the record exchange
+                                 (None for a single robot)
+            nb_best_matches, intra_min_inbetween: frontend.nb_best_matches /
+                frontend.intra_loop_min_inbetween_keyframes; 0 disables the intra-robot match
+        """
+        from . import _lib
+        self._lib = _lib
+        self._L = _lib.load()
+        self.pool = pool
+        self.robot_id, self.nb_robots = int(robot_id), int(nb_robots)
+        self.max_block = int(max_block)
+        self.comm_desc, self.comm_rec = comm_desc, comm_rec
+        self.candidate_selector = selector or AlgebraicConnectivityMaximization(
+            self.robot_id, self.nb_robots)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.cslam_shard_create(
+            pool.handle, comm_desc.handle if comm_desc else None,
+            comm_rec.handle if comm_rec else None, self.robot_id, self.nb_robots, self.max_block,
+            float(similarity_threshold), int(nb_best_matches), int(intra_min_inbetween),
+            ctypes.byref(h)))
+        self.handle = h
+        self._cap = int(self._L.cslam_shard_max_records(h))
+        self._buf = np.empty(self._cap, dtype=RECORD_DTYPE)
+        self._pending_items = []   # keyframe ids of published blocks, in order
+        if pool.n:
+            kfs = np.asarray([pool.items[i] for i in range(pool.n)], dtype=np.int32)
+            _lib.check(self._L.cslam_shard_set_keyframes(h, 0, _lib.ptr(kfs), len(kfs)))
+
+    def set_keyframes(self, first, keyframe_ids):
+        kfs = np.ascontiguousarray(keyframe_ids, dtype=np.int32)
+        self._lib.check(self._L.cslam_shard_set_keyframes(self.handle, int(first),
+                                                          self._lib.ptr(kfs), len(kfs)))
+
+    def publish(self, block, keyframe_ids, stream=None):
+        """block: CUDA float32 tensor [b, dim] (unit inner stride) or (device_ptr, row_stride)."""
+        if isinstance(block, tuple):
+            ptr, stride = block
+            b = len(keyframe_ids)
+        else:
+            ptr, stride, b = block.data_ptr(), (block.stride(0) if block.shape[0] else self.pool.dim), block.shape[0]
+            if b and (block.stride(1) != 1 or block.shape[1] != self.pool.dim):
+                raise ValueError("publish expects float32 [b, dim] with unit inner stride")
+        if b != len(keyframe_ids):
+            raise ValueError("publish: len(keyframe_ids) != rows of the block")
+        kfs = np.ascontiguousarray(keyframe_ids, dtype=np.int64)
+        self._lib.check(self._L.cslam_shard_publish(self.handle, ctypes.c_void_p(ptr), int(stride),
+                                                    self._lib.ptr(kfs) if b else None, int(b),
+                                                    ctypes.c_void_p(stream or 0)))
+        self._pending_items.append([int(k) for k in keyframe_ids])
+
+    def match(self, stream=None):
+        self._lib.check(self._L.cslam_shard_match(self.handle, ctypes.c_void_p(stream or 0)))
+        for kf in self._pending_items.pop(0):       # the library appended the own block
+            self.pool.items[self.pool.n] = kf
+            self.pool.n += 1
+
+    def fetch_records(self):
+        """All ranks' records of the oldest matched step as a structured array (rank order, then
+        descriptor order; identical on every rank).  Blocks until that step is done."""
+        n, step = ctypes.c_int64(), ctypes.c_int64()
+        self._lib.check(self._L.cslam_shard_fetch(self.handle, self._lib.ptr(self._buf.view(np.uint8)),
+                                                  self._cap, ctypes.byref(n), ctypes.byref(step)))
+        return self._buf[:n.value].copy()
+
+    def apply(self, records):
+        """Feed fetched records to the selector replica; returns (inter-robot edges produced by
+        THIS rank, intra-robot matches [(keyframe, matched keyframe, similarity)])."""
+        mine, local = [], []
+        for r in records:
+            r0, k0, r1, k1, w = int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(np.float32(r[4]))
+            if r0 == r1:
+                if r0 == self.robot_id:
+                    local.append((k0, k1, w))
+                continue
+            e = EdgeInterRobot(r0, k0, r1, k1, w)
+            self.candidate_selector.add_match(e)
+            mine.append(e)
+        return mine, local
+
+    def step(self, block, keyframe_ids, stream=None):
+        self.publish(block, keyframe_ids, stream)
+        self.match(stream)
+        return self.apply(self.fetch_records())
+
+    def is_broker(self):
+        return self.robot_id == 0
+
+    def select_candidates(self, budget, is_neighbor_in_range=None):
+        if is_neighbor_in_range is None:
+            is_neighbor_in_range = {r: True for r in range(self.nb_robots)}
+        return self.candidate_selector.select_candidates(int(budget), dict(is_neighbor_in_range))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.cslam_shard_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

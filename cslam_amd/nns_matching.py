@@ -128,11 +128,10 @@ class NearestNeighborsMatching(object):
 
     # -- add_item (nns_matching.py:23-42) ------------------------------------------------
     def add_item(self, vector, item):
-        """Add item to the matching list
+        """Append one descriptor to the pool (one H2D row copy; capacity doubles when full).
 
-        Args:
-            vector (np.array): descriptor
-            item: identification info (e.g., int)
+        vector: 1-D float array (any float dtype; stored as fp32).
+        item:   whatever the caller wants back from `search` for this row (a keyframe id).
         """
         vector = _to_numpy_f32(vector).reshape(-1)
         if self._pool is None:
@@ -160,15 +159,28 @@ class NearestNeighborsMatching(object):
             self.items[self.n] = it
             self.n += 1
 
-    def add_items_device(self, dev_ptr, n_rows, row_stride, items, stream=None):
-        """Append rows that already live in HBM (e.g. an all-gathered block)."""
+    def add_items_device(self, dev_ptr, n_rows, row_stride, items=None, stream=None):
+        """Append rows that already live in HBM (e.g. an all-gathered block).  `items=None` maps
+        every new row to its own row number (callers that only use row numbers)."""
         if self._pool is None:
             raise ValueError("pool dimension unknown; construct with dim=")
+        n_rows, row_stride = int(n_rows), int(row_stride)
+        if n_rows < 0 or (n_rows > 0 and row_stride < self.dim):
+            raise ValueError(f"add_items_device: row_stride {row_stride} < dim {self.dim}")
+        if items is not None and len(items) != n_rows:
+            raise ValueError("add_items_device: len(items) != n_rows")
+        if n_rows == 0:
+            return
         _lib.check(self._lib.cslam_pool_add_dev(self._pool, ctypes.c_void_p(dev_ptr), n_rows,
                                                 row_stride, ctypes.c_void_p(stream or 0)))
-        for it in items:
-            self.items[self.n] = it
-            self.n += 1
+        first = self.n
+        self.n = int(self._lib.cslam_pool_size(self._pool))   # the library is the source of truth
+        if self.n != first + n_rows:
+            raise RuntimeError("pool size out of step with the host mirror")
+        if items is None:
+            items = range(first, first + n_rows)
+        for i, it in enumerate(items):
+            self.items[first + i] = it
 
     def add_items_tensor(self, vectors, items):
         """Append the rows of a CUDA float32 tensor [B, dim] (e.g. descriptors straight out of the
@@ -186,6 +198,8 @@ class NearestNeighborsMatching(object):
             self._create(vectors.shape[1])
         if vectors.shape[1] != self.dim:
             raise ValueError(f"descriptor size {vectors.shape[1]} != pool dim {self.dim}")
+        if vectors.device.index != self.device_id:
+            raise ValueError(f"tensor lives on cuda:{vectors.device.index}, the pool on hip:{self.device_id}")
         self.add_items_device(vectors.data_ptr(), vectors.shape[0], vectors.stride(0), list(items),
                               stream=torch.cuda.current_stream().cuda_stream)
 
@@ -199,6 +213,8 @@ class NearestNeighborsMatching(object):
         if queries.dim() != 2 or queries.dtype != torch.float32 or queries.stride(1) != 1 \
                 or queries.shape[1] != self.dim:
             raise ValueError("search_best_batch_tensor expects float32 [M, dim] with unit inner stride")
+        if not queries.is_cuda or queries.device.index != self.device_id:
+            raise ValueError(f"queries must live on cuda:{self.device_id} (the pool's device)")
         idx = torch.empty((m, 1), dtype=torch.int32, device=queries.device)
         sim = torch.empty((m, 1), dtype=torch.float32, device=queries.device)
         _lib.check(self._lib.cslam_pool_search_dev(
@@ -231,14 +247,10 @@ class NearestNeighborsMatching(object):
         return idx[:, :kk], sim[:, :kk]
 
     def search(self, query, k):
-        """Search for nearest neighbors
+        """Cosine top-k of one query against rows [0, n).
 
-        Args:
-            query (np.array): descriptor to match
-            k (int): number of best matches to return
-
-        Returns:
-            list(int, np.array): best matches
+        Returns (items of the min(k, n) most similar rows, best first; their similarities as
+        np.float32[min(k, n)]); `([], [])` while the pool has no storage yet.
         """
         if len(self.data) == 0:
             return [], []
@@ -246,14 +258,8 @@ class NearestNeighborsMatching(object):
         return [self.items[int(r)] for r in rows[0]], sims[0]
 
     def search_best(self, query):
-        """Search for the nearest neighbor
-
-        Args:
-            query (np.array): descriptor to match
-
-        Returns:
-            int, np.array: best match
-        """
+        """`search(query, 1)` unpacked: (item, similarity) of the most similar row, or
+        (None, None) while the pool has no storage yet."""
         if len(self.data) == 0:
             return None, None
         items, similarities = self.search(query, 1)

@@ -37,6 +37,7 @@ extern "C" {
 #define CSLAM_E_DISCONNECTED (-4) /* Laplacian of a disconnected graph: the reference's SuperLU
                                      raises "Factor is exactly singular" here (acm.py:455 catches it) */
 #define CSLAM_E_NOCONV (-5)       /* eigen-solver did not reach the tolerance */
+#define CSLAM_E_COMM (-6)         /* RCCL missing or a collective failed (message has the reason) */
 
 const char* cslam_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -64,6 +65,7 @@ int cslam_pool_add_dev(cslam_pool_t* pool, const float* rows_dev, int64_t n_rows
 int64_t cslam_pool_size(const cslam_pool_t* pool);     /* self.n */
 int64_t cslam_pool_capacity(const cslam_pool_t* pool); /* len(self.data) */
 int cslam_pool_dim(const cslam_pool_t* pool);
+int cslam_pool_device(const cslam_pool_t* pool);       /* HIP device the pool lives on */
 /* `.data[first:first+n]` → host [n][dim] (tests/test_sparse_matching.py:36,49,66). */
 int cslam_pool_read_rows(const cslam_pool_t* pool, int64_t first, int64_t n, float* out);
 /* cached 1/max(||row||,1e-8) for rows [first, first+n) → host. */
@@ -103,6 +105,93 @@ int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launc
 /* Name (static string) of the dot-product kernel variant the last search launched, e.g.
  * "k_scan_dma<NS=8,NW=4,NST=2,nt>": what the roofline line of bench.py is about. */
 const char* cslam_pool_scan_kernel(const cslam_pool_t* pool);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-robot exchange: rank = robot = GPU, RCCL over xGMI.
+ * Replaces the ROS 2 fan-out of GlobalDescriptors (cslam/global_descriptor_loop_closure_
+ * detection.py:196-209) and InterRobotMatches (:223-283) between robots that share a node.
+ * RCCL is resolved with dlopen at the first call; CSLAM_E_COMM if it is missing.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cslam_comm cslam_comm_t;
+#define CSLAM_COMM_ID_BYTES 128
+/* pass as `stream` to run a collective on the communicator's own (non-blocking) stream */
+#define CSLAM_COMM_OWN_STREAM ((void*)(intptr_t)-1)
+
+/* Rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to every rank out of band. */
+int cslam_comm_unique_id(uint8_t* id_out);
+/* Collective over all ranks: every process calls it with the same id and its own rank. */
+int cslam_comm_init(int rank, int nranks, const uint8_t* unique_id, int device_id,
+                    cslam_comm_t** out);
+/* Same communicator object over a caller-supplied transport instead of RCCL: `allgather` must
+ * leave rank r's bytes at recv_dev + r * bytes_per_rank on every rank before work enqueued on
+ * `stream` after it runs (it may synchronise the stream).  Used by the tests (robot shards as
+ * threads of one process on one GPU), by bench.py's one-GPU rehearsal (gloo through host memory)
+ * and for fabrics other than xGMI (robots on different hosts).  Returns 0 on success. */
+typedef int (*cslam_allgather_fn)(void* user, const void* send_dev, void* recv_dev,
+                                  int64_t bytes_per_rank, void* stream);
+int cslam_comm_init_custom(int rank, int nranks, int device_id, cslam_allgather_fn allgather,
+                           void* user, cslam_comm_t** out);
+int cslam_comm_destroy(cslam_comm_t* comm);
+int cslam_comm_rank(const cslam_comm_t* comm);
+int cslam_comm_size(const cslam_comm_t* comm);
+void* cslam_comm_stream(const cslam_comm_t* comm); /* hipStream_t of the communicator */
+/* payload bytes received by all-gathers so far, number of collectives, RCCL version code */
+int cslam_comm_stats(const cslam_comm_t* comm, int64_t* bytes_gathered, int64_t* n_collectives,
+                     int32_t* rccl_version);
+/* recv_dev[r * bytes_per_rank ...] = rank r's send_dev; in place when
+ * send_dev == recv_dev + rank * bytes_per_rank.  Asynchronous on `stream`. */
+int cslam_comm_allgather(cslam_comm_t* comm, const void* send_dev, void* recv_dev,
+                         int64_t bytes_per_rank, void* stream);
+/* The descriptor exchange of one step: this rank contributes b rows (row_stride floats apart);
+ * all_dev [nranks][b_max][dim] receives every rank's block (rows past its count zeroed),
+ * counts_dev [nranks] the counts. */
+int cslam_allgather_descriptors(cslam_comm_t* comm, const float* local_dev, int64_t row_stride,
+                                int32_t b, int32_t b_max, int32_t dim, float* all_dev,
+                                int32_t* counts_dev, void* stream);
+
+/* Plain copy helper for transports written in Python: kind 0 = host→device, 1 = device→host,
+ * 2 = device→device; asynchronous on `stream` unless sync != 0. */
+int cslam_device_copy(void* dst, const void* src, int64_t bytes, int kind, void* stream, int sync);
+
+/* The 20-byte inter-robot match record of gdlcd.py:276 (InterRobotMatch message fields).
+ * robot0_id == robot1_id marks an intra-robot match (LocalKeyframeMatch, gdlcd.py:145-168). */
+typedef struct {
+    int32_t robot0_id;
+    int32_t robot0_keyframe_id;
+    int32_t robot1_id;
+    int32_t robot1_keyframe_id;
+    float weight;
+} cslam_match_record_t;
+
+/* Rank-local half of the sharded matching step (csrc/shard.hip): robot `robot_id` owns `pool`
+ * and nothing of the other robots' (the reference mirrors every peer pool,
+ * loop_closure_sparse_matching.py:26-32).  comm_desc / comm_rec: two communicators over the same
+ * ranks (descriptor and record exchange overlap each other); both NULL for a single robot.
+ * nb_best_matches > 0 enables the intra-robot match of own keyframes
+ * (match_local_loop_closures, lcsm.py:78-97) when max_block + nb_best_matches <= 64. */
+typedef struct cslam_shard cslam_shard_t;
+int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t* comm_rec,
+                       int robot_id, int nb_robots, int max_block, double similarity_threshold,
+                       int nb_best_matches, int intra_min_inbetween, cslam_shard_t** out);
+int cslam_shard_destroy(cslam_shard_t* shard);
+/* keyframe ids of pool rows [first, first+n) that were added outside the shard */
+int cslam_shard_set_keyframes(cslam_shard_t* shard, int64_t first, const int32_t* keyframe_ids,
+                              int64_t n);
+/* Step part 1 — publish this robot's new block (b <= max_block rows in HBM, keyframe ids on
+ * the host) and start the all-gather of everybody's blocks.  Asynchronous. */
+int cslam_shard_publish(cslam_shard_t* shard, const float* new_rows_dev, int64_t row_stride,
+                        const int64_t* keyframe_ids, int b, void* stream);
+/* Step part 2 — for the oldest published step: append the own block, scan the pool for all
+ * gathered descriptors, build the match records on the device, start their all-gather and the
+ * copy to pinned host memory.  Asynchronous on `stream`. */
+int cslam_shard_match(cslam_shard_t* shard, void* stream);
+/* Step part 3 — records of ALL ranks for the oldest matched step, rank order then descriptor
+ * order (identical on every rank).  Blocks until that step has finished on the device. */
+int cslam_shard_fetch(cslam_shard_t* shard, cslam_match_record_t* out, int64_t cap, int64_t* n_out,
+                      int64_t* step_index);
+int64_t cslam_shard_max_records(const cslam_shard_t* shard);
+int cslam_shard_pending(const cslam_shard_t* shard, int64_t* published, int64_t* matched,
+                        int64_t* fetched);
 
 /* ------------------------------------------------------------------------------------------
  * MAC problem  — cslam/mac/mac.py:19-233

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tools") not in sys.path:     # workload builders shared with bench.py
+    sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 
 def pytest_configure(config):

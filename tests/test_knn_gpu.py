@@ -192,6 +192,38 @@ def test_range_search_and_sharded_step_on_gpu(gpu):
     assert sh.matcher.size == 4
 
 
+def test_search_best_device_queries_strided_and_unaligned(gpu):
+    """search_best (k = 1) through the device-pointer ABI on the DMA path: a strided query
+    view is read in place, a view that starts off a 16-byte boundary goes through the staging
+    kernel; both equal the oracle bit for bit, ties resolve to the lowest row."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    from cslam_amd import _lib
+    rs = np.random.RandomState(77)
+    n, d = 18000, 512
+    X = rs.rand(n, d).astype(np.float32)
+    X[9000] = X[17]                                     # tie → row 17
+    m = _pool(gpu, X, dim=d, capacity_hint=n)
+    Qh = rs.rand(6, d).astype(np.float32)
+    Qh[2] = X[17]
+    big = torch.zeros((6, d + 64 + 1), device="cuda")
+    o_idx, o_sim, _ = oracle_knn.search(X, Qh, 1)
+    for off in (0, 1):                                  # 0: aligned, in place; 1: staged
+        view = big[:, off:off + d]
+        view.copy_(torch.from_numpy(Qh))
+        idx = torch.empty((6, 1), dtype=torch.int32, device="cuda")
+        sim = torch.empty((6, 1), dtype=torch.float32, device="cuda")
+        _lib.check(gpu.cslam_pool_search_dev(m.handle, ctypes.c_void_p(view.data_ptr()),
+                                             view.stride(0), 6, 1, ctypes.c_void_p(idx.data_ptr()),
+                                             ctypes.c_void_p(sim.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert gpu.cslam_pool_scan_kernel(m.handle).decode().endswith("best>")
+        np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+        assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
+        assert idx[2, 0].item() == 17
+    m.close()
+
+
 def test_device_append_is_ordered_before_host_api(gpu):
     """A device-pointer append on a busy caller stream followed, with NO synchronisation, by the
     host-pointer API (own non-blocking stream): the search must see the appended rows, and a
@@ -257,6 +289,10 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
     (17000, 4096, 3, 1),      # cfg2 row shape
     (40000, 768, 16, 3),      # odd number of slices: the last 512-float chunk is a half chunk
     (140000, 256, 9, 10),     # more than 128 rows per wave: two panels per wave
+    (16384, 256, 16, 1),      # k = 1: fused arg-max epilogue, queries read in place
+    (20011, 512, 5, 1),       # k = 1, partial strips, 5 of 16 query columns valid
+    (20000, 250, 7, 1),       # k = 1, dim padded to 256: staged queries
+    (140000, 256, 1, 1),      # k = 1, two panels per wave (query norm only from the first)
 ])
 def test_dma_scan_matches_oracle(gpu, n, d, m, k):
     """k_scan_dma (the default dots kernel from 16384 rows when dim % 256 == 0) against the C

@@ -272,7 +272,7 @@ def test_cfg3_fiedler_matches_scipy_eigsh(gpu):
     """BASELINE.json configs[2]: 50k-node pose graph, 200k candidates; lambda_2 must match
     scipy eigsh (shift-invert) — north_star tolerance 1e-5, checked to 1e-9."""
     import scipy.sparse.linalg as spla
-    from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+    from mac_bench_util import cfg3_graph, greedy_w
     from cslam_amd.mac.mac import MAC
     n, fixed, cand = cfg3_graph()
     assert n == 50_000 and len(cand) == 200_000
@@ -338,7 +338,7 @@ def test_persistent_solver_shares_the_gpu_with_concurrent_scans(gpu):
     results must not change and nothing may hang or fall back silently into an error."""
     import threading
     import time as _time
-    from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+    from mac_bench_util import cfg3_graph, greedy_w
     from cslam_amd.mac.mac import MAC
     from cslam_amd.nns_matching import NearestNeighborsMatching
     n, fixed, cand = cfg3_graph(poses_per_robot=6000, nb_candidates=30_000, seed=3)

@@ -1,0 +1,194 @@
+"""The device-side sharded matching step (csrc/shard.hip, csrc/comm.hip) through the C ABI.
+
+* RCCL itself: a one-rank communicator on the one GPU of the test box (two ranks cannot share a
+  device under RCCL) — unique id, init, the descriptor all-gather, in-place byte all-gather.
+* The step protocol with R > 1: robot shards as THREADS of this process sharing the GPU, each
+  with its own pool / shard / communicators over the `LocalGroup` transport, compared with the
+  reference semantics replayed sequentially on the oracle
+  (cslam/loop_closure_sparse_matching.py:37-97; replay order documented in
+  cslam_amd/multi_robot.py and SURVEY.md §8e).
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import knn as oracle_knn
+from test_multi_robot import DIM, MAXB, THR, _sequential_reference_with, make_blocks
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_one_rank_communicator(gpu):
+    torch = pytest.importorskip("torch")
+    from cslam_amd import _lib
+    from cslam_amd.multi_robot import RcclComm
+    uid = RcclComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = RcclComm(0, 1, uid, 0)
+    assert gpu.cslam_comm_rank(comm.handle) == 0 and gpu.cslam_comm_size(comm.handle) == 1
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.rand(3, 80).astype(np.float32)).cuda()      # row stride 80 > dim 64
+    all_rows = torch.full((1, 5, 64), -7.0, device="cuda")
+    counts = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(gpu.cslam_allgather_descriptors(comm.handle, ctypes.c_void_p(x.data_ptr()), 80, 3, 5, 64,
+                                               ctypes.c_void_p(all_rows.data_ptr()),
+                                               ctypes.c_void_p(counts.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert counts.cpu().tolist() == [3]
+    got = all_rows.cpu().numpy()[0]
+    np.testing.assert_array_equal(got[:3], x.cpu().numpy()[:, :64])
+    assert np.all(got[3:] == 0.0)
+    # byte all-gather on the communicator's own stream, in place
+    buf = torch.arange(100, dtype=torch.uint8, device="cuda")
+    _lib.check(gpu.cslam_comm_allgather(comm.handle, ctypes.c_void_p(buf.data_ptr()),
+                                        ctypes.c_void_p(buf.data_ptr()), 100, _lib.CSLAM_COMM_OWN_STREAM))
+    torch.cuda.synchronize()
+    assert buf.cpu().tolist() == list(range(100))
+    st = comm.stats()
+    assert st["collectives"] == 3 and st["bytes_gathered"] == 5 * 64 * 4 + 4 + 100
+    assert st["rccl_version"] > 0
+    comm.close()
+
+
+def _intra_reference(blocks, world, steps, k, min_inbetween, thr):
+    """match_local_loop_closures (lcsm.py:78-97) replayed per robot: every new keyframe is
+    inserted, then searched in the pool as it is (itself included), top-k, self dropped when
+    first, first far-enough and similar-enough match kept."""
+    out = {r: [] for r in range(world)}
+    for r in range(world):
+        rows = np.zeros((0, DIM), np.float32)
+        kfs = []
+        for t in range(steps):
+            x, ids = blocks[(t, r)]
+            for i, kf in enumerate(ids):
+                rows = np.vstack([rows, x[i:i + 1]])
+                kfs.append(kf)
+                idx, sim, cnt = oracle_knn.search(rows, x[i:i + 1], k)
+                lst = [(kfs[int(j)], float(s)) for j, s in zip(idx[0][:cnt[0]], sim[0][:cnt[0]])]
+                if lst and lst[0][0] == kf:
+                    lst = lst[1:]
+                for kfm, s in lst:
+                    if abs(kfm - kf) < min_inbetween or s < thr:
+                        continue
+                    out[r].append((kf, kfm, np.float32(s)))
+                    break
+    return out
+
+
+def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM, thr=THR):
+    torch = pytest.importorskip("torch")
+    from cslam_amd.multi_robot import CallbackComm, DeviceShard, LocalGroup
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    grp_d, grp_r = LocalGroup(world), LocalGroup(world)
+    results, local, errors = [None] * world, [None] * world, []
+    records = [None] * world
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            pool = NearestNeighborsMatching(dim=dim)
+            cd = CallbackComm(rank, world, 0, grp_d.transport(rank))
+            cr = CallbackComm(rank, world, 0, grp_r.transport(rank))
+            sh = DeviceShard(pool, rank, world, max_block, thr, cd, cr, nb_best_matches=nb_best,
+                             intra_min_inbetween=min_inbetween)
+            mine, recs = [], []
+            for t in range(steps):
+                x, kfs = blocks[(t, rank)]
+                xd = torch.from_numpy(x).cuda() if len(kfs) else torch.zeros((0, dim), device="cuda")
+                sh.publish(xd, kfs)
+                sh.match()
+                r = sh.fetch_records()
+                recs.append(r)
+                _, loc = sh.apply(r)
+                mine.extend(loc)
+            results[rank] = {k: float(v.weight) for k, v in sh.candidate_selector.candidate_edges.items()}
+            local[rank] = mine
+            records[rank] = np.concatenate(recs) if recs else None
+            assert pool.n == sum(len(blocks[(t, rank)][1]) for t in range(steps))
+            sh.close(); cd.close(); cr.close(); pool.close()
+        except Exception as e:  # surface worker failures in the main thread
+            errors.append(e)
+            grp_d.barrier.abort()
+            grp_r.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    assert not errors, errors
+    return results, local, records
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_device_shard_matches_reference_semantics(gpu, world):
+    """Fused mode (one scan per step, top-(b+k) split on the device): inter-robot candidate set
+    identical to the sequential reference, replicas identical on every rank, every rank fetched
+    the same record stream, intra-robot matches equal to match_local_loop_closures replayed."""
+    steps, k, gap = 10, 4, 3
+    blocks = make_blocks(world, steps, seed=5)
+    results, local, records = _run_shards(world, steps, blocks, MAXB, k, gap)
+    union, _ = _sequential_reference_with(blocks, world, steps)
+    assert len(union) > 5
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for key in union:
+            assert abs(results[r][key] - union[key]) <= 1e-7
+        assert results[r] == results[0]
+        assert records[r].tobytes() == records[0].tobytes()
+    intra = _intra_reference(blocks, world, steps, k, gap, THR)
+    assert sum(len(v) for v in intra.values()) > 3
+    for r in range(world):
+        assert [(a, b) for a, b, _ in local[r]] == [(a, b) for a, b, _ in intra[r]]
+        for (_, _, s), (_, _, so) in zip(local[r], intra[r]):
+            assert np.float32(s) == so
+
+
+def test_device_shard_bulk_blocks(gpu):
+    """Blocks too large for the fused top-K (max_block + k > 64): old-row and new-row matches come
+    from two searches around the append; same candidate set as the sequential reference."""
+    world, steps, maxb = 3, 3, 70
+    rs = np.random.RandomState(9)
+    blocks, nxt = {}, [0] * world
+    for t in range(steps):
+        for r in range(world):
+            b = int(rs.randint(40, maxb + 1))
+            blocks[(t, r)] = (rs.rand(b, DIM).astype(np.float32), list(range(nxt[r], nxt[r] + b)))
+            nxt[r] += b
+    results, local, _ = _run_shards(world, steps, blocks, maxb, 10, 5)
+    union, _ = _sequential_reference_with(blocks, world, steps)
+    assert len(union) > 20
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for key in union:
+            assert abs(results[r][key] - union[key]) <= 1e-7
+        assert local[r] == []                      # intra-robot matching is a fused-mode feature
+
+
+def test_device_shard_single_robot_and_pipelining(gpu):
+    """One robot, no communicator: nothing to match against, blocks are appended; up to four steps
+    may be in flight, a fifth publish without a fetch is refused loudly."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd import _lib
+    from cslam_amd.multi_robot import DeviceShard
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    pool = NearestNeighborsMatching(dim=256)
+    sh = DeviceShard(pool, 0, 1, 4, 0.5, nb_best_matches=3, intra_min_inbetween=1)
+    rs = np.random.RandomState(1)
+    x = rs.rand(16, 256).astype(np.float32)
+    x[9] = x[2]                                           # keyframe 9 revisits keyframe 2
+    xd = torch.from_numpy(x).cuda()
+    for t in range(4):
+        sh.publish(xd[4 * t:4 * t + 4], list(range(4 * t, 4 * t + 4)))
+    with pytest.raises(_lib.CslamHipError):
+        sh.publish(xd[:4], [100, 101, 102, 103])
+    local = []
+    for t in range(4):
+        sh.match()
+    for t in range(4):
+        _, loc = sh.apply(sh.fetch_records())
+        local.extend(loc)
+    assert pool.n == 16 and [pool.items[i] for i in range(16)] == list(range(16))
+    assert (9, 2) in [(a, b) for a, b, _ in local]
+    assert sh.candidate_selector.candidate_edges == {}
+    sh.close(); pool.close()

@@ -4,7 +4,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cslam_amd.mac.bench_util import fiedler_bench  # noqa: E402
+from mac_bench_util import fiedler_bench  # noqa: E402
 
 variants = [("graph", {"CSLAM_MAC_PERSISTENT": "0"}),
             ("persist_e4", {"CSLAM_MAC_PERSIST_ELEMS": "4"}),

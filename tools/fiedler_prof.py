@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CSLAM_MAC_PROF"] = "1"
-from cslam_amd.mac.bench_util import cfg3_graph, greedy_w
+from mac_bench_util import cfg3_graph, greedy_w
 from cslam_amd.mac.mac import MAC
 n, fixed, cand = cfg3_graph()
 w0 = greedy_w(cand, 500)

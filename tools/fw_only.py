@@ -6,7 +6,7 @@ import time
 from contextlib import redirect_stdout
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cslam_amd.mac.bench_util import cfg3_graph, greedy_w  # noqa: E402
+from mac_bench_util import cfg3_graph, greedy_w  # noqa: E402
 from cslam_amd.mac.mac import MAC  # noqa: E402
 
 n, fixed, cand = cfg3_graph()

@@ -1,14 +1,14 @@
 """cfg3-scale MAC workload (BASELINE.json configs[2]): 2 robots x 25 000-pose odometry chains,
 one fixed inter-robot edge, 200 000 distinct inter-robot candidates with U(0,1) weights,
-budget 500.  Used by bench.py (extras) and tests/test_mac_gpu.py."""
+budget 500.  Used by bench.py (extras) and tests/test_mac_gpu.py; lives outside the product package."""
 import io
 import time
 from contextlib import redirect_stdout
 
 import numpy as np
 
-from .mac import MAC
-from .utils import Edge
+from cslam_amd.mac.mac import MAC
+from cslam_amd.mac.utils import Edge
 
 
 def cfg3_graph(nb_robots=2, poses_per_robot=25_000, nb_candidates=200_000, seed=0):
@@ -81,7 +81,7 @@ def acm_select_bench(poses_per_robot=25_000, nb_candidates=200_000, budget=500, 
     """End-to-end `AlgebraicConnectivityMaximization.select_candidates` at cfg3 scale: graph
     assembly on the host + MAC create + 20 Frank-Wolfe iterations + rounding + bookkeeping —
     what the node pays per selection round (cslam/algebraic_connectivity_maximization.py:467-542)."""
-    from ..algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
+    from cslam_amd.algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
                                                        EdgeInterRobot)
     rs = np.random.RandomState(seed)
     acm = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=2)
