@@ -6,7 +6,7 @@
 // ||x||^2 is a wave64 butterfly sum cached at add time, sim = (dot * rn(x)) * rn(q).
 //
 // Kernels
-//   k_inv_norm      one wave per row, 16-B coalesced loads, xor-butterfly reduce
+//   k_append_rows   add_item: copy + zero-pad + cached 1/||row|| (wave64 order) in one launch
 //   k_stage_queries pads the query block to [16*T][dp] in HBM (L2-resident) + 1/||q||
 //   k_scan<T,U>     HBM-bound streaming scan: every wave owns a contiguous, byte-balanced row
 //                   range, walks it in 16-row strips, A operand straight from HBM to VGPRs
@@ -55,22 +55,9 @@ __device__ inline uint64_t make_comp(float s, uint32_t row) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1 / max(||row||, 1e-8), wave64 order (oracle/knn_oracle.c: sumsq_wave_order)
+// 1 / max(||row||, 1e-8); the sum of squares arrives in wave64 order (oracle/knn_oracle.c:
+// sumsq_wave_order): lane l takes floats 256t + 4l + c, xor butterfly 32 .. 1
 // ---------------------------------------------------------------------------------------------
-__device__ inline float wave_sumsq(const float* row, int dp, int lane) {
-    float acc = 0.0f;
-    for (int base = 4 * lane; base < dp; base += 256) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(row + base);
-        acc = __builtin_fmaf(v.x, v.x, acc);
-        acc = __builtin_fmaf(v.y, v.y, acc);
-        acc = __builtin_fmaf(v.z, v.z, acc);
-        acc = __builtin_fmaf(v.w, v.w, acc);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
-    return acc;
-}
-
 __device__ inline float inv_norm_from_sumsq(float ss) {
     // plain sqrtf and '/' are IEEE correctly rounded under hipcc's default
     // -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn/__fdiv_rn intrinsics are NOT).
@@ -79,34 +66,56 @@ __device__ inline float inv_norm_from_sumsq(float ss) {
     return 1.0f / nrm;
 }
 
-__global__ __launch_bounds__(256) void k_inv_norm(const float* __restrict__ rows, int64_t stride,
-                                                  int64_t first, int64_t count, int dp,
-                                                  float* __restrict__ out) {
-    int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (w >= count) return;
-    int64_t r = first + w;
-    float ss = wave_sumsq(rows + r * stride, dp, lane);
-    if (lane == 0) out[r] = inv_norm_from_sumsq(ss);
-}
+__device__ inline float ld_or_zero(const float* s, int k, int dim) { return k < dim ? s[k] : 0.0f; }
 
-// copy `count` rows of `dim` floats (stride src_stride) into the padded pool layout
-__global__ __launch_bounds__(256) void k_copy_pad(const float* __restrict__ src,
-                                                  int64_t src_stride, int dim,
-                                                  float* __restrict__ dst, int64_t dst_stride,
-                                                  int dp, int64_t count) {
-    int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
+// append = copy + pad + cached inverse norm in ONE launch: one wave per row, lane l moves floats
+// 256t + 4l .. +3 — exactly the lane assignment of the norm's wave64 order (wave_sumsq), so the
+// sum of squares is accumulated from the registers that are being stored.  16-byte loads when
+// the source allows it (vec_ok), 8 loads in flight per lane.
+__global__ __launch_bounds__(256) void k_append_rows(const float* __restrict__ src,
+                                                     int64_t src_stride, int dim,
+                                                     float* __restrict__ dst, int64_t dst_stride,
+                                                     int dp, int64_t first, int64_t count,
+                                                     float* __restrict__ inv_norm, int vec_ok) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (w >= count) return;
     const float* s = src + w * src_stride;
-    float* d = dst + w * dst_stride;
-    for (int k = lane; k < dp; k += 64) d[k] = (k < dim) ? s[k] : 0.0f;
+    float* d = dst + (first + w) * dst_stride;
+    float ss = 0.0f;
+    for (int base0 = 4 * lane; base0 < dp; base0 += 256 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = base0 + 256 * u;
+            if (k < dp) {
+                if (vec_ok && k + 3 < dim)
+                    v[u] = *reinterpret_cast<const f32x4*>(s + k);
+                else
+                    v[u] = f32x4{ld_or_zero(s, k, dim), ld_or_zero(s, k + 1, dim),
+                                 ld_or_zero(s, k + 2, dim), ld_or_zero(s, k + 3, dim)};
+            } else {
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // fmaf(0,0,ss) == ss: no-op past the row
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = base0 + 256 * u;
+            if (k < dp) *reinterpret_cast<f32x4*>(d + k) = v[u];
+            ss = __builtin_fmaf(v[u].x, v[u].x, ss);
+            ss = __builtin_fmaf(v[u].y, v[u].y, ss);
+            ss = __builtin_fmaf(v[u].z, v[u].z, ss);
+            ss = __builtin_fmaf(v[u].w, v[u].w, ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, kWave);
+    if (lane == 0) inv_norm[first + w] = inv_norm_from_sumsq(ss);
 }
 
 // queries → staging [mq_pad][dp] (zero padded, rows >= m are zero) and rnq[mq_pad].
 // One 256-thread block per query row; wave 0 also computes ||q||^2 in wave64 order straight
 // from the source values (loads batched 8 deep: the chain order is per lane, not per load).
-__device__ inline float ld_or_zero(const float* s, int k, int dim) { return k < dim ? s[k] : 0.0f; }
 
 __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__ q,
                                                        int64_t q_stride, int dim, int m,
@@ -1282,15 +1291,6 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     return CSLAM_OK;
 }
 
-int launch_norms(cslam_pool* p, int64_t first, int64_t count, hipStream_t st) {
-    if (count <= 0) return CSLAM_OK;
-    unsigned blocks = (unsigned)((count + 3) / 4);
-    hipLaunchKernelGGL(k_inv_norm, dim3(blocks), dim3(256), 0, st, p->rows, p->xs, first,
-                       count, p->dp, p->inv_norm);
-    CSLAM_HIP_TRY(hipGetLastError());
-    return CSLAM_OK;
-}
-
 template <int T, int S, int U>
 void launch_scan_t(cslam_pool* p, const float* Q, int m_valid, float* dots, int64_t dots_stride,
                    int64_t n_waves, hipStream_t st) {
@@ -1802,14 +1802,13 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
         CSLAM_TRY(p->h_rows.reserve(bytes));
         CSLAM_HIP_TRY(hipMemcpyAsync(p->h_rows.p, rows + done * p->dim, bytes, hipMemcpyHostToDevice,
                                      p->stream));
-        hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, p->stream,
-                           p->h_rows.as<float>(), (int64_t)p->dim, p->dim,
-                           p->rows + (p->n + done) * p->xs, p->xs, p->dp, c);
+        hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, p->stream,
+                           p->h_rows.as<float>(), (int64_t)p->dim, p->dim, p->rows, p->xs, p->dp,
+                           p->n + done, c, p->inv_norm, (p->dim & 3) == 0 ? 1 : 0);
         CSLAM_HIP_TRY(hipGetLastError());
         // the staging buffer is reused by the next chunk
         if (done + c < n_rows) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     }
-    CSLAM_TRY(launch_norms(p, p->n, n_rows, p->stream));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     p->dev_pending = false;  // the stream waited for it and has drained
     p->n += n_rows;
@@ -1825,10 +1824,10 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     CSLAM_TRY(order_after_dev(p, st));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
-    hipLaunchKernelGGL(k_copy_pad, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
-                       row_stride, p->dim, p->rows + p->n * p->xs, p->xs, p->dp, n_rows);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(rows_dev) & 15) == 0 && (row_stride & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
+                       row_stride, p->dim, p->rows, p->xs, p->dp, p->n, n_rows, p->inv_norm, vec_ok);
     CSLAM_HIP_TRY(hipGetLastError());
-    CSLAM_TRY(launch_norms(p, p->n, n_rows, st));
     p->n += n_rows;
     return mark_dev(p, st);
 }

@@ -47,13 +47,6 @@ __global__ __launch_bounds__(256) void k_pack_block(const float* __restrict__ sr
     }
 }
 
-// keyframe id of the pool rows appended by this step
-__global__ void k_set_kf(int32_t* __restrict__ kf_of_row, int64_t n0, const int64_t* __restrict__ meta,
-                         int b) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < b) kf_of_row[n0 + i] = (int32_t)meta[1 + i];
-}
-
 // One thread per gathered descriptor i = s * b_max + j (owner s, position j).
 // FUSED: topk_idx/topk_sim hold the sorted top-K of the pool AFTER the own block was appended;
 //        the best old row (< n0) and the best new row (>= n0) are both inside it (K > b).
@@ -63,12 +56,19 @@ __global__ void k_set_kf(int32_t* __restrict__ kf_of_row, int64_t n0, const int6
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_make_records(
     int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
-    const int32_t* __restrict__ kf_of_row, double thr, const int32_t* __restrict__ topk_idx,
+    int32_t* __restrict__ kf_of_row, int b_own, double thr, const int32_t* __restrict__ topk_idx,
     const float* __restrict__ topk_sim, int K, int k_local, int min_inbetween,
     const int32_t* __restrict__ idx_a, const float* __restrict__ sim_a,
     const int32_t* __restrict__ idx_c, const float* __restrict__ sim_c,
     cslam_match_record_t* __restrict__ recs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // keyframe id of the pool rows appended by this step: rows >= n0 are looked up in the own
+    // meta block below (their table entries are written here, for the steps to come)
+    const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
+    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
+    auto kf_at = [&](int32_t row) {
+        return row >= n0 ? (int32_t)own_meta[1 + (row - n0)] : kf_of_row[row];
+    };
     if (i >= nb_robots * b_max) return;
     const int s = i / b_max, j = i % b_max;
     const int64_t* meta = all_meta + (int64_t)s * (1 + b_max);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_make_records(
             const bool a_ok = ia >= 0 && (double)sa >= thr;
             if (a_ok) {  // this robot's add_other_robot_global_descriptor (lcsm.py:69-75)
                 r0.robot0_id = me;
-                r0.robot0_keyframe_id = kf_of_row[ia];
+                r0.robot0_keyframe_id = kf_at(ia);
                 r0.robot1_id = s;
                 r0.robot1_keyframe_id = kf_s;
                 r0.weight = sa;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_make_records(
                 r1.robot0_id = s;
                 r1.robot0_keyframe_id = kf_s;
                 r1.robot1_id = me;
-                r1.robot1_keyframe_id = kf_of_row[ic];
+                r1.robot1_keyframe_id = kf_at(ic);
                 r1.weight = sc;
             }
         } else if (FUSED && k_local > 0) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_make_records(
                 if (row > self_row) continue;  // a later keyframe of this block: not there yet
                 ++kept;
                 if (kept == 1 && row == self_row) continue;  // lcsm.py:83-84
-                const int32_t kf = kf_of_row[row];
+                const int32_t kf = kf_at(row);
                 const int d = kf > kf_s ? kf - kf_s : kf_s - kf;
                 if (d < min_inbetween) continue;
                 const float sv = topk_sim[(int64_t)i * K + t];
@@ -375,21 +375,18 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
     const int64_t n0 = cslam_pool_size(sh->pool);
     const float* my_rows = s.all_rows + (int64_t)me * bm * dim;
-    const int64_t* my_meta = s.all_meta + (int64_t)me * (1 + bm);
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
-    const unsigned gm = (unsigned)((M + 255) / 256);
+    const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);
     if (sh->fused) {
         // append first, then ONE scan: the sorted top-K (K > b) of every gathered descriptor
         // holds both its best older row and its best row of the new block
         if (s.b > 0) {
             CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
             CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
-            hipLaunchKernelGGL(k_set_kf, dim3((unsigned)((s.b + 255) / 256)), dim3(256), 0, st,
-                               sh->kf_of_row, n0, my_meta, s.b);
         }
         CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows, dim, M, sh->K, s.topk_idx, s.topk_sim, st));
         hipLaunchKernelGGL((k_make_records<true>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
-                           n0, sh->kf_of_row, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
+                           n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
                            sh->min_inbetween, nullptr, nullptr, nullptr, nullptr, my_recs);
     } else {
         // bulk blocks: best old row of every FOREIGN descriptor (the own block is skipped: two
@@ -405,8 +402,6 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         if (s.b > 0) {
             CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
             CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
-            hipLaunchKernelGGL(k_set_kf, dim3((unsigned)((s.b + 255) / 256)), dim3(256), 0, st,
-                               sh->kf_of_row, n0, my_meta, s.b);
             if (lo_n > 0)
                 CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, lo_n, 1, n0,
                                                       n0 + s.b, s.idx_c, s.sim_c, st));
@@ -416,7 +411,7 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
                                                       s.sim_c + hi_first, st));
         }
         hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
-                           n0, sh->kf_of_row, sh->thr, nullptr, nullptr, 1, 0, 0, s.idx_a, s.sim_a,
+                           n0, sh->kf_of_row, s.b, sh->thr, nullptr, nullptr, 1, 0, 0, s.idx_a, s.sim_a,
                            s.idx_c, s.sim_c, my_recs);
     }
     CSLAM_HIP_TRY(hipGetLastError());

@@ -9,8 +9,8 @@ matching and selection underneath are the HIP implementations of this package.  
   * only the "descriptor arrives on cslam/processed_global_descriptor" technique is on the path
     (NetVLAD / ScanContext front ends are out of scope, DESIGN.md §8);
   * the two buffer-pruning loops of the reference delete from a SortedDict while iterating its
-    live key view (gdlcd.py:176-178,188-190); here the keys are snapshotted first — same
-    result without relying on that container's tolerance;
+    live key view (gdlcd.py:176-178,188-190), which removes every other stale key per call;
+    `_prune` walks the keys by position to give the same result explicitly;
   * `lcm` may be injected (tests drive the surface on CPU with a stub matcher).
 Works with real rclpy (`node` is the rclpy Node) or with a test double exposing
 create_publisher / create_subscription / create_timer / get_parameter / get_logger.
@@ -144,9 +144,19 @@ class GlobalDescriptorLoopClosureDetection(object):
     # ---- periodic publication (gdlcd.py:170-283) -------------------------------------------
     @staticmethod
     def _prune(buffer, first_needed):
+        """The reference deletes from the SortedDict while iterating its live key view
+        (gdlcd.py:176-178, 188-190): the iterator walks the sorted key list by position, every
+        deletion shifts the rest one slot left, so only every other stale key goes per call
+        (the rest follow on later calls).  Reproduced position by position —
+        tests/golden/gdlcd_ref.json pins it (keys 0..9, bound 9 → 1, 3, 5, 7, 9 remain)."""
         if first_needed >= buffer.peekitem(0)[0]:
-            for k in [k for k in buffer.keys() if k < first_needed]:
-                del buffer[k]
+            keys = buffer.keys()
+            pos = 0
+            while pos < len(buffer):
+                k = keys[pos]
+                if k < first_needed:
+                    del buffer[k]
+                pos += 1
 
     def delete_useless_descriptors(self):
         """Drop descriptors every other robot has been sent (gdlcd.py:170-178)."""

@@ -8,6 +8,10 @@ Shims (all outside /root/reference):
   * NearestNeighborsMatching.device forced to CPU right after construction
     (cslam/nns_matching.py:16 hard-wires 'cuda')
   * fake `node` with get_logger() for LoopClosureSparseMatching (lcsm.py:72)
+  * gen_gdlcd only: the ROS 2 packages the node surface imports (rclpy, cslam_common_interfaces,
+    std_msgs, diagnostic_msgs, cv2, cv_bridge — none exists in this image) are replaced by
+    field-container message classes and empty modules; the surface runs on the node double of
+    tests/fake_ros.py.  No arithmetic lives in those packages.
 
 Usage:  python tests/golden/gen_golden.py
 """
@@ -508,6 +512,175 @@ def gen_vpr():
     print("vpr_ref.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+# ----------------------------------------------------------------------------------------------
+# ROS surface: the reference's GlobalDescriptorLoopClosureDetection / NeighborManager /
+# NeighborMonitor driven through the scripted scenarios of tests/ros_scenarios.py
+# ----------------------------------------------------------------------------------------------
+# loop_closure_detection_node.py:20-44 — the node's parameter table (names and defaults)
+REF_NODE_PARAMETERS = {
+    'frontend.similarity_threshold': 0.9, 'frontend.global_descriptor_technique': 'cosplace',
+    'frontend.netvlad.pca_checkpoint': '', 'frontend.nn_checkpoint': 'models/resnet18_64.pth',
+    'robot_id': 0, 'max_nb_robots': 10, 'frontend.inter_robot_loop_closure_budget': 5,
+    'frontend.inter_robot_detection_period_sec': 5, 'frontend.nb_best_matches': 10,
+    'frontend.image_crop_size': 376, 'frontend.intra_loop_min_inbetween_keyframes': 10,
+    'neighbor_management.max_heartbeat_delay_sec': 5.0, 'neighbor_management.init_delay_sec': 5.0,
+    'neighbor_management.heartbeat_period_sec': 0.5,
+    'frontend.detection_publication_period_sec': 1.0,
+    'frontend.detection_publication_max_elems_per_msg': 10,
+    'neighbor_management.enable_neighbor_monitoring': False,
+    'frontend.enable_intra_robot_loop_closures': False,
+    'frontend.global_descriptors_topic': "global_descriptors",
+    'frontend.inter_robot_matches_topic': "inter_robot_matches",
+    'frontend.enable_sparsification': True, 'frontend.use_vertex_cover_selection': True,
+    'frontend.sensor_type': "stereo", 'evaluation.enable_logs': False,
+    'evaluation.enable_sparsification_comparison': False,
+}
+
+
+def _msg_class(name, **fields):
+    def __init__(self, **kw):
+        for k, d in fields.items():
+            setattr(self, k, d() if callable(d) else d)
+        for k, v in kw.items():
+            if k not in fields:
+                raise AttributeError(f"{name} has no field {k}")
+            setattr(self, k, v)
+    return type(name, (object,), {"__init__": __init__})
+
+
+def _install_ros_stand_ins():
+    """Field containers with the message definitions' field names (cslam_common_interfaces/msg,
+    std_msgs, diagnostic_msgs) and empty rclpy / cv2 / cv_bridge modules."""
+    def module(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    ids = _msg_class("UInt32MultiArrayLike", ids=list)
+    msgs = dict(
+        GlobalDescriptor=_msg_class("GlobalDescriptor", keyframe_id=0, robot_id=0, descriptor=list),
+        GlobalDescriptors=_msg_class("GlobalDescriptors", descriptors=list),
+        InterRobotMatch=_msg_class("InterRobotMatch", robot0_id=0, robot0_keyframe_id=0, robot1_id=0,
+                                   robot1_keyframe_id=0, weight=0.0),
+        InterRobotMatches=_msg_class("InterRobotMatches", robot_id=0, matches=list),
+        InterRobotLoopClosure=_msg_class("InterRobotLoopClosure", robot0_id=0, robot0_keyframe_id=0,
+                                         robot1_id=0, robot1_keyframe_id=0, success=False),
+        LocalDescriptorsRequest=_msg_class("LocalDescriptorsRequest", keyframe_id=0,
+                                           matches_robot_id=list, matches_keyframe_id=list),
+        LocalKeyframeMatch=_msg_class("LocalKeyframeMatch", keyframe0_id=0, keyframe1_id=0),
+        RobotIdsAndOrigin=_msg_class("RobotIdsAndOrigin", robots=ids, origins=ids),
+        KeyframeRGB=_msg_class("KeyframeRGB"), KeyframePointCloud=_msg_class("KeyframePointCloud"))
+    pkg = module("cslam_common_interfaces")
+    pkg.msg = module("cslam_common_interfaces.msg", **msgs)
+    std = module("std_msgs")
+    std.msg = module("std_msgs.msg", String=_msg_class("String", data=""),
+                     UInt32=_msg_class("UInt32", data=0))
+    dia = module("diagnostic_msgs")
+    dia.msg = module("diagnostic_msgs.msg", KeyValue=_msg_class("KeyValue", key="", value=""))
+    rclpy = module("rclpy")
+    rclpy.node = module("rclpy.node", Node=type("Node", (object,), {}))
+    rclpy.clock = module("rclpy.clock", Clock=type("Clock", (object,), {"now": lambda self: 0.0}))
+    module("cv2")
+    module("cv_bridge", CvBridge=type("CvBridge", (object,), {}))
+    ns = types.SimpleNamespace(**msgs)
+    ns.UInt32 = std.msg.UInt32
+    ns.String = std.msg.String
+    return ns
+
+
+def gen_gdlcd():
+    sys.path.insert(0, os.path.dirname(HERE))     # tests/: fake_ros, ros_scenarios
+    msgs = _install_ros_stand_ins()
+    from fake_ros import FakeBus, FakeNode as BusNode
+    import ros_scenarios
+    from cslam.global_descriptor_loop_closure_detection import GlobalDescriptorLoopClosureDetection
+
+    def make_robot(bus, rid, nb, overrides):
+        ros_params = dict(REF_NODE_PARAMETERS)
+        ros_params.update({"robot_id": rid, "max_nb_robots": nb})
+        ros_params.update(overrides)
+        node = BusNode(bus, f"/r{rid}", ros_params)
+        # loop_closure_detection_node.py:45-89: the flat dict handed to the surface
+        params = {k: v for k, v in ros_params.items()
+                  if k not in ('frontend.netvlad.pca_checkpoint', 'frontend.global_descriptors_topic',
+                               'frontend.inter_robot_matches_topic')}
+        params["frontend.sensor_type"] = params["frontend.sensor_type"].lower()
+        g = GlobalDescriptorLoopClosureDetection(params, node)
+        g.lcm.local_nnsm.device = torch.device("cpu")
+        for m in g.lcm.other_robots_nnsm.values():
+            m.device = torch.device("cpu")
+        return node, g
+
+    desc = np.load(os.path.join(HERE, "lcsm_desc.npz"))["desc"]
+    traces = ros_scenarios.run_all(make_robot, msgs, FakeBus, desc)
+    with open(os.path.join(HERE, "gdlcd_ref.json"), "w") as f:
+        json.dump(traces, f)
+    print("gdlcd_ref.json:", {k: sorted(v) for k, v in traces.items()})
+
+
+# ----------------------------------------------------------------------------------------------
+# cfg4: R reference LoopClosureSparseMatching instances fed the block stream of
+# tests/test_multi_robot.py in the arrival order the sharded protocol documents (SURVEY §8e)
+# ----------------------------------------------------------------------------------------------
+def gen_cfg4():
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.append(os.path.dirname(os.path.dirname(HERE)))   # repo root: oracle/ (block generator's import)
+    import test_multi_robot as tm
+
+    def make(robot_id, nb, k, gap):
+        p = {"robot_id": robot_id, "max_nb_robots": nb, "frontend.sensor_type": "stereo",
+             "frontend.similarity_threshold": tm.THR, "frontend.nb_best_matches": k,
+             "frontend.intra_loop_min_inbetween_keyframes": gap,
+             "frontend.enable_sparsification": True,
+             "evaluation.enable_sparsification_comparison": False}
+        l = LoopClosureSparseMatching(p, FakeNode())
+        l.local_nnsm.device = torch.device("cpu")
+        for m in l.other_robots_nnsm.values():
+            m.device = torch.device("cpu")
+        return l
+
+    out = {}
+    for world, steps, seed, k, gap in ((3, 12, 0, 4, 3), (4, 10, 5, 4, 3), (2, 10, 5, 4, 3)):
+        blocks = tm.make_blocks(world, steps, seed=seed)
+        robots = [make(r, world, k, gap) for r in range(world)]
+        intra = {r: [] for r in range(world)}
+        for t in range(steps):
+            for r in range(world):                       # (1) deliveries, rank order
+                x, kfs = blocks[(t, r)]
+                for s in range(world):
+                    if s == r:
+                        continue
+                    for i, kf in enumerate(kfs):
+                        robots[s].add_other_robot_global_descriptor(
+                            GlobalDescriptor(int(kf), r, x[i].tolist()))
+            for r in range(world):                       # (2) own insertions (+ intra-robot match)
+                x, kfs = blocks[(t, r)]
+                for i, kf in enumerate(kfs):
+                    robots[r].add_local_global_descriptor(x[i], int(kf))
+                    m, _ = robots[r].match_local_loop_closures(x[i], int(kf))
+                    if m is not None:
+                        intra[r].append([int(kf), int(m)])
+        union = {}
+        per_robot = []
+        for r in range(world):
+            ce = robots[r].candidate_selector.candidate_edges
+            per_robot.append(sorted(list(k_) + [float(v.weight)] for k_, v in ce.items()))
+            for k_, v in ce.items():
+                key = str(tuple(int(a) for a in k_))
+                union[key] = max(union.get(key, -1.0), float(v.weight))
+        out[f"world{world}_steps{steps}_seed{seed}"] = dict(
+            world=world, steps=steps, seed=seed, nb_best_matches=k, min_inbetween=gap,
+            threshold=tm.THR, union=union, per_robot=per_robot,
+            intra={str(r): v for r, v in intra.items()},
+            pool_sizes=[int(robots[r].local_nnsm.n) for r in range(world)])
+    with open(os.path.join(HERE, "cfg4_ref.json"), "w") as f:
+        json.dump(out, f)
+    print("cfg4_ref.json:", {k: (len(v["union"]), sum(len(x) for x in v["intra"].values()))
+                             for k, v in out.items()})
+
+
 if __name__ == "__main__":
     random.seed(0)
     np.random.seed(0)
@@ -518,3 +691,5 @@ if __name__ == "__main__":
     gen_broker()
     gen_cfg1()
     gen_vpr()
+    gen_cfg4()
+    gen_gdlcd()      # last: installs stand-ins for the ROS packages

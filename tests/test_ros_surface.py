@@ -88,7 +88,8 @@ def test_topics_and_chunked_publication_with_resend_window():
     assert [len(m.descriptors) for m in msgs] == [4, 4, 2]     # chunks of 4
     assert l1.batches == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]  # one device call per message
     assert l0.other == []                                     # own messages are ignored
-    assert len(g0.global_descriptors_buffer) == 1             # everything all robots have is pruned
+    # pruning deletes while iterating like the reference (gdlcd.py:176-178): every other stale key
+    assert list(g0.global_descriptors_buffer.keys()) == [1, 3, 5, 7, 9]
     # a resend of the same keyframes is deduplicated on the receiving side
     g1.global_descriptor_callback(msgs[0])
     assert l1.batches[-1] == []

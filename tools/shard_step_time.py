@@ -1,0 +1,90 @@
+"""Device-side cost of the sharded step (csrc/shard.hip) on ONE GPU: robot 0 of R with a loopback
+transport that fills the other ranks' slots with device-to-device copies of its own block (no
+real peer, no RCCL) — what append + one scan (top-(b+k)) + record building cost next to the plain
+16-query search_best step.  Usage: python tools/shard_step_time.py [R] [steps]"""
+import ctypes
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from cslam_amd import _lib  # noqa: E402
+from cslam_amd.multi_robot import CallbackComm, DeviceShard  # noqa: E402
+from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+N, D = 100_000, 4096
+per_rank = 16 // R
+L = _lib.load()
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(0)
+X = torch.rand((N, D), device=dev, generator=g)
+pool = NearestNeighborsMatching(dim=D, capacity_hint=N + (steps + 40) * per_rank)
+st = torch.cuda.current_stream().cuda_stream
+pool.add_items_device(X.data_ptr(), N, D, items=None, stream=st)
+
+
+def loopback(send, recv, nbytes, stream):
+    for r in range(R):
+        if recv + r * nbytes != send:
+            _lib.check(L.cslam_device_copy(recv + r * nbytes, send, nbytes, 2, stream, 0))
+
+
+cd = CallbackComm(0, R, 0, loopback)
+cr = CallbackComm(0, R, 0, loopback)
+sh = DeviceShard(pool, 0, R, per_rank, 0.0, cd, cr, nb_best_matches=10, intra_min_inbetween=10)
+blocks = torch.rand((8, per_rank, D), device=dev, generator=g)
+kf = [N]
+pub = [0]
+
+
+def publish():
+    sh.publish(blocks[pub[0] % 8], list(range(kf[0], kf[0] + per_rank)), st)
+    kf[0] += per_rank
+    pub[0] += 1
+
+
+def run(n):
+    matched = fetched = recs = 0
+    publish()
+    for t in range(n):
+        publish()
+        sh.match(st)
+        matched += 1
+        if matched - fetched > 1:
+            recs += len(sh.fetch_records())
+            fetched += 1
+    sh.match(st)            # the block published last
+    matched += 1
+    while fetched < matched:
+        recs += len(sh.fetch_records())
+        fetched += 1
+    torch.cuda.synchronize()
+    return recs
+
+
+run(10)
+t0 = time.perf_counter()
+recs = run(steps)
+dt = (time.perf_counter() - t0) / (steps + 1)
+print(f"R={R} per_rank={per_rank}: {dt * 1e3:.4f} ms per step, {recs / (steps + 1):.1f} records per step, "
+      f"kernel {L.cslam_pool_scan_kernel(pool.handle).decode()}")
+
+q = torch.rand((16, D), device=dev, generator=g)
+oi = torch.empty((16, 1), dtype=torch.int32, device=dev)
+os_ = torch.empty((16, 1), dtype=torch.float32, device=dev)
+for _ in range(5):
+    _lib.check(L.cslam_pool_search_dev(pool.handle, ctypes.c_void_p(q.data_ptr()), D, 16, 1,
+                                       ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(os_.data_ptr()),
+                                       ctypes.c_void_p(st)))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    _lib.check(L.cslam_pool_search_dev(pool.handle, ctypes.c_void_p(q.data_ptr()), D, 16, 1,
+                                       ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(os_.data_ptr()),
+                                       ctypes.c_void_p(st)))
+torch.cuda.synchronize()
+print(f"plain search_best step on the same pool: {(time.perf_counter() - t0) / steps * 1e3:.4f} ms")
