@@ -154,6 +154,21 @@ def test_sharded_step_protocol_matches_sequential_reference(world):
     assert all(res[r]["bytes"] == steps * per_step for r in range(world))
 
 
+def test_sequential_restatement_equals_the_reference_run():
+    """The yardstick itself is pinned: tests/golden/cfg4_ref.json holds the candidate sets of R
+    REFERENCE LoopClosureSparseMatching instances (cslam/loop_closure_sparse_matching.py:37-76,
+    run in the build container) fed this file's block stream in the protocol's arrival order."""
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                      "cfg4_ref.json")))["world3_steps12_seed0"]
+    union, sizes = sequential_reference(3, 12)
+    ref_union = {tuple(int(x) for x in k.strip("()").split(",")): w for k, w in ref["union"].items()}
+    assert set(union) == set(ref_union) and len(union) > 100
+    for k, w in ref_union.items():
+        assert abs(union[k] - w) <= 1e-6        # torch-CPU cosine vs the pinned fp32 chain
+    assert sizes == ref["pool_sizes"]
+
+
 def test_single_rank_degenerates_to_local_insert():
     from cslam_amd.multi_robot import ShardedLoopClosureMatching
 

@@ -77,6 +77,13 @@ def _intra_reference(blocks, world, steps, k, min_inbetween, thr):
     return out
 
 
+def _cfg4_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "cfg4_ref.json")))
+
+
 def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM, thr=THR):
     torch = pytest.importorskip("torch")
     from cslam_amd.multi_robot import CallbackComm, DeviceShard, LocalGroup
@@ -136,6 +143,15 @@ def test_device_shard_matches_reference_semantics(gpu, world):
             assert abs(results[r][key] - union[key]) <= 1e-7
         assert results[r] == results[0]
         assert records[r].tobytes() == records[0].tobytes()
+    # ... and with the REFERENCE itself: R reference LoopClosureSparseMatching instances fed the
+    # same stream in the documented arrival order (tests/golden/gen_golden.py::gen_cfg4)
+    ref = _cfg4_fixture()[f"world{world}_steps{steps}_seed5"]
+    ref_union = {tuple(int(x) for x in key.strip("()").split(",")): w for key, w in ref["union"].items()}
+    assert set(results[0]) == set(ref_union)
+    for key, w in ref_union.items():
+        assert abs(results[0][key] - w) <= 1e-6
+    for r in range(world):
+        assert [[a, b] for a, b, _ in local[r]] == ref["intra"][str(r)]
     intra = _intra_reference(blocks, world, steps, k, gap, THR)
     assert sum(len(v) for v in intra.values()) > 3
     for r in range(world):
