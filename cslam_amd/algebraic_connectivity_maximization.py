@@ -48,6 +48,92 @@ class EdgeInterRobot(NamedTuple):
     __hash__ = tuple.__hash__
 
 
+class _CandidateStore(dict):
+    """`candidate_edges` — a dict keyed by the normalised edge key like the reference's
+    (acm.py:45), which ALSO keeps the (r0, kf0, r1, kf1, weight) rows in one float64 array in
+    dict order: a slot per key (overwriting keeps the slot, like a dict keeps the position of
+    an existing key; a re-inserted key goes to the end in both).  `select_candidates` at cfg3
+    scale (200k candidates) reads `live_rows()` instead of walking 200k Python objects."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self._rows = np.empty((1024, 5), dtype=np.float64)
+        self._alive = np.zeros(1024, dtype=bool)
+        self._slot = {}
+        self._n = 0
+        if args or kwargs:
+            self.update(*args, **kwargs)
+
+    def _grow(self):
+        cap = 2 * len(self._alive)
+        rows = np.empty((cap, 5), dtype=np.float64)
+        rows[:self._n] = self._rows[:self._n]
+        alive = np.zeros(cap, dtype=bool)
+        alive[:self._n] = self._alive[:self._n]
+        self._rows, self._alive = rows, alive
+
+    def _compact(self):
+        keep = np.nonzero(self._alive[:self._n])[0]
+        self._rows[:len(keep)] = self._rows[keep]
+        self._alive[:len(keep)] = True
+        self._alive[len(keep):self._n] = False
+        self._n = len(keep)
+        self._slot = {k: i for i, k in enumerate(self.keys())}   # dict order == slot order
+
+    def __setitem__(self, key, edge):
+        s = self._slot.get(key)
+        if s is None:
+            if self._n == len(self._alive):
+                if 2 * len(self) < self._n:
+                    self._compact()
+                else:
+                    self._grow()
+            s = self._n
+            self._n += 1
+            self._slot[key] = s
+            self._alive[s] = True
+        self._rows[s] = edge
+        super().__setitem__(key, edge)
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        self._alive[self._slot.pop(key)] = False
+
+    _missing = object()
+
+    def pop(self, key, default=_missing):
+        if key in self:
+            value = self[key]
+            del self[key]
+            return value
+        if default is self._missing:
+            raise KeyError(key)
+        return default
+
+    def popitem(self):
+        key = next(reversed(self))
+        return key, self.pop(key)
+
+    def clear(self):
+        super().clear()
+        self._slot.clear()
+        self._alive[:] = False
+        self._n = 0
+
+    def update(self, *args, **kwargs):
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = v
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+    def live_rows(self):
+        """float64 [len(self), 5] in dict order."""
+        return self._rows[:self._n][self._alive[:self._n]]
+
+
 class AlgebraicConnectivityMaximization(object):
 
     def __init__(self,
@@ -76,7 +162,7 @@ class AlgebraicConnectivityMaximization(object):
         self.device_id = device_id
 
         self.fixed_edges = []
-        self.candidate_edges = {}
+        self._candidate_edges = _CandidateStore()
         self.already_considered_matches = set()
         self.total_nb_poses = 0
         self.nb_poses = {r: 0 for r in range(max_nb_robots)}
@@ -85,6 +171,16 @@ class AlgebraicConnectivityMaximization(object):
         self.log_greedy_edges = []
         self.log_mac_edges = []
         self.last_solver_exceptions = 0  # how many rungs of the retry ladder the last call used
+
+    @property
+    def candidate_edges(self):
+        return self._candidate_edges
+
+    @candidate_edges.setter
+    def candidate_edges(self, mapping):
+        """Callers may assign a plain dict (the reference's attribute is one)."""
+        self._candidate_edges = mapping if isinstance(mapping, _CandidateStore) \
+            else _CandidateStore(mapping)
 
     # ---- small helpers (acm.py:75-129) -----------------------------------------------------
     def edge_key(self, edge):
@@ -341,7 +437,7 @@ class AlgebraicConnectivityMaximization(object):
                 or not self.params["frontend.enable_sparsification"]:
             return None
         nr = self.max_nb_robots
-        cand = self._inter_robot_rows(self.candidate_edges.values(), len(self.candidate_edges))
+        cand = self.candidate_edges.live_rows()
         fixed = self._inter_robot_rows(self.fixed_edges, len(self.fixed_edges))
         considered = np.array([bool(is_other_robot_considered[r]) for r in range(nr)])
         # check_graph_disconnections (acm.py:390-416)

@@ -34,7 +34,16 @@ constexpr int kChunkKb = 32;       // fold the MFMA partial into the total every
 constexpr int kSelectPart = 4096;  // elements per select block (256 threads x 16)
 constexpr int kSelectMaxK = 128;   // above this the bitonic path is used
 constexpr int kMaxQueriesPerPass = 64;
-constexpr int64_t kQueryChunk = 256;  // queries per similarity workspace chunk
+constexpr int64_t kQueryChunk = 1024;  // most queries per similarity-workspace chunk
+// Queries per chunk for the current row window: as many as a 2-GiB dots workspace holds, between
+// 256 and kQueryChunk, in whole 128-query GEMM tiles.  (Round 1 chunked at 256: a 100k-row GEMM
+// launch then had 782 tiles for 512 tile slots — 3.05 waves of tiles, a quarter of the chip idle
+// in the last one; at 1024 queries it is 12.2 waves.)
+inline int64_t query_chunk(int64_t sims_stride) {
+    int64_t c = ((int64_t)1 << 31) / (sims_stride * (int64_t)sizeof(float));
+    c = c / 128 * 128;
+    return c < 256 ? 256 : (c > kQueryChunk ? kQueryChunk : c);
+}
 
 __host__ __device__ inline int64_t pad16(int64_t d) { return (d + 15) / 16 * 16; }
 
@@ -1078,6 +1087,218 @@ __global__ __launch_bounds__(256, 2) void k_gemm32(const float* __restrict__ X, 
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_dma: the MFMA-bound bulk path (>= 96 queries) with BOTH operands staged by LDS-DMA.
+//   Block = 4 waves (one per SIMD, 2 x 2), block tile 256 rows x 128 queries, K stage = 32
+//   floats: a stage tile is 384 "tile rows" (256 X rows then 128 query rows) x 128 B, i.e. whole
+//   128-B lines, moved by 48 global_load_lds_dwordx4 of 8 rows each (12 per wave) into a 3-slot
+//   LDS ring (3 x 48 KiB): two stages are in flight while the third is being multiplied, ONE
+//   raw s_barrier per stage (8192 MFMA cycles per wave) behind a counted vmcnt — no register
+//   staging, no ds_write, no vmcnt(0) in the loop.  The LDS image of a DMA instruction is linear,
+//   so the 16-byte segments of every row are XOR-swizzled on the SOURCE side (segment ^ (row/2 & 7))
+//   and un-swizzled by the ds_read_b128 address: the 16-lane groups of ds_read_b128 then touch 16
+//   different 16-B slots (conflict free, checked by hand against the lane groups of the guide).
+//   Every wave owns 128 x 64 outputs = 4 x 2 MFMA tiles of v_mfma_f32_32x32x2_f32; operand order
+//   inside a 16-float block is the (k, k+4) pairing of k_gemm32, chunk folds every 32 k-blocks:
+//   identical bits to every other dots kernel.  XCD-aware tile order as in k_gemm32.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGdCols = 128, kGdK = 32;
+
+// TM = 32-row MFMA tiles per wave along the rows (block rows = 64 * TM), SLOTS = LDS ring depth.
+//   <4, 3>: 256 x 128 tile, 3 x 48 KiB, one block (4 waves, 1 per SIMD) per CU, two stages in flight
+//   <2, 2>: 128 x 128 tile, 2 x 32 KiB, two blocks per CU (2 waves per SIMD cover each other's
+//           barrier and DMA-issue stalls), one stage in flight — the default (122 vs 120 TF)
+//   <1, 2>:  64 x 128 tile for the LAST, partial wave of tiles: the rows that do not fill a whole
+//           number of tile waves are cut into half-height tiles so that they spread over the
+//           chip (12.2 waves of tiles cost 12.5 instead of 13)
+template <int TM, int SLOTS>
+__global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
+    const float* __restrict__ X, int64_t xs, int64_t n, int dp, const float* __restrict__ Q,
+    int m_valid, float* __restrict__ dots, int64_t dots_stride, int n_rowblk, int n_colblk) {
+    constexpr int kRows = 64 * TM;                    // X rows per block
+    constexpr int kTileRows = kRows + kGdCols;        // rows of 128 B per stage
+    constexpr int kStageB = kTileRows * kGdK * 4;
+    constexpr int kPW = kTileRows / 32;               // DMA instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) char gd_lds[];
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int t = b >> 3;
+    const int colblk = t % n_colblk;
+    const int rowblk = (t / n_colblk) * 8 + xcd;
+    if (rowblk >= n_rowblk) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nkb = dp >> 4;
+    const int nstage = (nkb + 1) >> 1;
+
+    // ---- DMA side: this wave moves tile rows [8*kPW*wave, 8*kPW*(wave+1)) of every stage ------
+    const int rr = lane >> 3, pos = lane & 7;
+    const float* src[kPW];
+    int seg_off[kPW];  // float offset of this lane's (swizzled) segment inside a stage
+#pragma unroll
+    for (int i = 0; i < kPW; ++i) {
+        const int trow = (kPW * wave + i) * 8 + rr;
+        const int seg = pos ^ ((trow >> 1) & 7);
+        seg_off[i] = seg * 4;
+        if (trow < kRows) {
+            int64_t row = (int64_t)rowblk * kRows + trow;
+            if (row >= n) row = n - 1;  // clamp: results of clamped rows are not stored
+            src[i] = X + row * xs;
+        } else {
+            src[i] = Q + (int64_t)(colblk * kGdCols + trow - kRows) * dp;
+        }
+    }
+    // quarter `part` of this wave's kPW pieces for `stage`
+    auto issue_part = [&](int stage, int slot, int part) {
+        char* dst = gd_lds + slot * kStageB + (kPW * wave) * 1024;
+#pragma unroll
+        for (int i = part * kPW / 4; i < (part + 1) * kPW / 4; ++i) {
+            int k = stage * kGdK + seg_off[i];
+            if (k >= dp) k -= 16;  // odd number of k-blocks: the missing half re-reads the first
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src[i] + k),
+                (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int stage, int slot) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(stage, slot, part);
+    };
+
+    // ---- MFMA side ---------------------------------------------------------------------------
+    const int swz = (r32 >> 1) & 7;
+    int a_row[TM], b_row[2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = (wr * 32 * TM + i * 32 + r32) * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_row[j] = (kRows + wc * 64 + j * 32 + r32) * 128;
+    int seg_rd[2][2];  // [k-block in stage][v0 / v1] byte offset of the un-swizzled segment
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) seg_rd[kb][half] = ((kb * 4 + h + 2 * half) ^ swz) * 16;
+
+    f32x16 acc[TM][2], tot[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                tot[i][j][e] = 0.f;
+            }
+
+    // one k-block (16 floats) of the stage at `base`: 2*(TM+2) fragment reads, 16*TM MFMAs.  With
+    // pre_stage >= 0 the wave's DMA pieces of that stage are issued a few at a time in the
+    // shadow of the MFMAs (issued in one burst before them they kept the matrix pipe idle).
+    auto kblock = [&](const char* base, int kb, int pre_stage, int pre_slot) {
+        f32x4 a0[TM], a1[TM], b0[2], b1[2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a0[i] = *reinterpret_cast<const f32x4*>(base + a_row[i] + seg_rd[kb][0]);
+            a1[i] = *reinterpret_cast<const f32x4*>(base + a_row[i] + seg_rd[kb][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b0[j] = *reinterpret_cast<const f32x4*>(base + b_row[j] + seg_rd[kb][0]);
+            b1[j] = *reinterpret_cast<const f32x4*>(base + b_row[j] + seg_rd[kb][1]);
+        }
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j4], b0[j][j4], acc[i][j],
+                                                                     0, 0, 0);
+            if (pre_stage >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_part(pre_stage, pre_slot, j4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j4], b1[j][j4], acc[i][j],
+                                                                     0, 0, 0);
+        }
+    };
+    auto fold = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                tot[i][j] = tot[i][j] + acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            }
+    };
+
+    constexpr int kAhead = SLOTS - 1;  // stages issued ahead of the one being multiplied
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i)
+        if (i < nstage) issue(i, i);
+    int slot = 0;
+    const int nfull = nkb >> 1;  // stages with both k-blocks; an odd last k-block is peeled below
+    // two loop levels (16 stages = 32 k-blocks = one 512-float chunk, then the fold) so that the
+    // accumulators are carried by ONE plain inner loop and stay where the MFMA wants them
+    for (int s0 = 0; s0 < nfull; s0 += 16) {
+        const int s1 = s0 + 16 < nfull ? s0 + 16 : nfull;
+        for (int s = s0; s < s1; ++s) {
+            // this wave's pieces of stage s have landed (later stages' may still fly) ...
+            if (SLOTS == 3 && s + 1 < nstage)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and so have everybody's; everybody is also done reading stage s-1
+            __builtin_amdgcn_s_barrier();
+            const char* base = gd_lds + slot * kStageB;
+            // stage s+kAhead goes into the slot of stage s-1 while k-block 0 is multiplied
+            kblock(base, 0, s + kAhead < nstage ? s + kAhead : -1, slot == 0 ? SLOTS - 1 : slot - 1);
+            kblock(base, 1, -1, 0);
+            slot = slot == SLOTS - 1 ? 0 : slot + 1;
+        }
+        if (s1 == s0 + 16) fold();  // a whole chunk (kChunkKb k-blocks)
+    }
+    if (nkb & 1) {  // the row ends with half a stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        kblock(gd_lds + slot * kStageB, 0, -1, 0);
+    }
+    if ((nkb & 31) != 0) fold();  // the last, shorter chunk
+
+    // epilogue: lane holds D[row = (e&3) + 8*(e>>2) + 4h][col = r32] of every 32x32 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = colblk * kGdCols + wc * 64 + j * 32 + r32;
+            if (q < m_valid) {
+                float* out = dots + (int64_t)q * dots_stride;
+                const int64_t rb = (int64_t)rowblk * kRows + wr * 32 * TM + i * 32 + 4 * h;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int64_t row = rb + 8 * e4;
+                    if (row + 3 < n) {
+                        *reinterpret_cast<f32x4*>(out + row) =
+                            f32x4{tot[i][j][4 * e4], tot[i][j][4 * e4 + 1], tot[i][j][4 * e4 + 2],
+                                  tot[i][j][4 * e4 + 3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row + e < n) out[row + e] = tot[i][j][4 * e4 + e];
+                    }
+                }
+            }
+        }
+}
+
 // cosine scaling of raw dots in place: sims[q][i] = (dot * rnx[i]) * rnq[q]
 __global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t stride, int64_t n,
                                                const float* __restrict__ rnx,
@@ -1093,6 +1314,28 @@ __global__ __launch_bounds__(256) void k_scale(float* __restrict__ sims, int64_t
 // ---------------------------------------------------------------------------------------------
 // exact top-k by rounds of block arg-max over composites
 // ---------------------------------------------------------------------------------------------
+// 64-lane maximum of a 64-bit composite on the VALU (DPP) — `__shfl_xor` of a 64-bit value is two
+// LDS-crossbar ds_bpermute per step, 12 dependent ones per round of the select.  0 is the
+// identity (an empty composite).  Result in every lane.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline uint64_t dpp_mov_u64(uint64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+}
+__device__ inline uint64_t wave_max_u64(uint64_t m) {
+    uint64_t o;
+    o = dpp_mov_u64<0xB1>(m);        m = o > m ? o : m;   // quad_perm [1,0,3,2]
+    o = dpp_mov_u64<0x4E>(m);        m = o > m ? o : m;   // quad_perm [2,3,0,1]
+    o = dpp_mov_u64<0x141>(m);       m = o > m ? o : m;   // row_half_mirror
+    o = dpp_mov_u64<0x140>(m);       m = o > m ? o : m;   // row_mirror: every lane = max of its row
+    o = dpp_mov_u64<0x142, 0xA>(m);  m = o > m ? o : m;   // row_bcast15: rows 1, 3 take rows 0, 2
+    o = dpp_mov_u64<0x143, 0xC>(m);  m = o > m ? o : m;   // row_bcast31: rows 2, 3 take rows 0..1
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <bool FROM_SIMS, bool FINAL>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
                                                 int64_t sims_stride,
@@ -1128,11 +1371,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
         uint64_t m = v[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) m = v[e] > m ? v[e] : m;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            uint64_t o = __shfl_xor(m, off, kWave);
-            m = o > m ? o : m;
-        }
+        m = wave_max_u64(m);
         if (lane == 0) wmax[rd & 1][wave] = m;
         __syncthreads();
         uint64_t win = wmax[rd & 1][0];
@@ -1538,15 +1777,65 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
                            m, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>(), vec_ok,
                            (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
-        const int n_rowblk = (int)((p->vn + 127) / 128);
-        const int n_colblk = mq_pad / 128;
-        const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
         bool prof = p->prof_on && p->prof_n < p->prof_max;
         if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-        p->last_scan_kernel = "k_gemm32";
-        hipLaunchKernelGGL(k_gemm32, dim3((unsigned)nblocks), dim3(256), 0, st,
-                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, p->qstage.as<float>(), m,
-                           dots, dots_stride, n_rowblk, n_colblk);
+        // CSLAM_GEMM=32 keeps the register-staged 128 x 128 kernel (A/B runs); the LDS-DMA kernel
+        // needs dots rows it can store 16 bytes at a time (the sims workspace is 64-float aligned)
+        const bool use_dma_gemm = gemm_env != 32 && (dots_stride & 3) == 0 &&
+                                  (reinterpret_cast<uintptr_t>(dots) & 15) == 0;
+        if (use_dma_gemm) {
+            // default: 128 x 128 tiles, two blocks per CU; CSLAM_GEMM=4: 256 x 128, one per CU
+            const int tm = gemm_env == 4 ? 4 : 2;
+            const int n_colblk = mq_pad / kGdCols;
+            auto launch = [&](int tmv, int64_t row0, int64_t nrows) -> int {
+                const int rows = 64 * tmv;
+                const int n_rowblk = (int)((nrows + rows - 1) / rows);
+                const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
+                const size_t lds = (size_t)(tmv == 4 ? 3 : 2) * (rows + kGdCols) * kGdK * 4;
+                const float* xr = p->rows + (p->v0 + row0) * p->xs;
+                float* dr = dots + row0;
+#define CSLAM_GD_LAUNCH(TMV, SL)                                                                   \
+    do {                                                                                           \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<TMV, SL>,                    \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                              (int)lds));                                          \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL((k_gemm_dma<TMV, SL>), dim3((unsigned)nblocks), dim3(256), lds, st, xr, \
+                           p->xs, nrows, p->dp, p->qstage.as<float>(), m, dr, dots_stride,         \
+                           n_rowblk, n_colblk);                                                    \
+    } while (0)
+                if (tmv == 4) CSLAM_GD_LAUNCH(4, 3);
+                else if (tmv == 2) CSLAM_GD_LAUNCH(2, 2);
+                else CSLAM_GD_LAUNCH(1, 2);
+#undef CSLAM_GD_LAUNCH
+                return CSLAM_OK;
+            };
+            // whole waves of tiles with the main shape, the remainder with half-height tiles
+            const int rows = 64 * tm;
+            const int64_t slots = (int64_t)p->cus * (tm == 4 ? 1 : 2);
+            const int64_t n_rowblk = (p->vn + rows - 1) / rows;
+            int64_t rb_main = n_rowblk;
+            if (tm == 2 && slots % n_colblk == 0) {
+                const int64_t full_waves = n_rowblk * n_colblk / slots;
+                const int64_t rb = full_waves * slots / n_colblk;
+                if (full_waves >= 1 && rb < n_rowblk) rb_main = rb;
+            }
+            const int64_t rows_main = std::min<int64_t>(p->vn, rb_main * rows);
+            p->last_scan_kernel = tm == 4 ? "k_gemm_dma<TM=4,SLOTS=3>" : "k_gemm_dma<TM=2,SLOTS=2>";
+            CSLAM_TRY(launch(tm, 0, rows_main));
+            if (rows_main < p->vn) CSLAM_TRY(launch(1, rows_main, p->vn - rows_main));
+        } else {
+            const int n_rowblk = (int)((p->vn + 127) / 128);
+            const int n_colblk = mq_pad / 128;
+            const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
+            p->last_scan_kernel = "k_gemm32";
+            hipLaunchKernelGGL(k_gemm32, dim3((unsigned)nblocks), dim3(256), 0, st,
+                               p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, p->qstage.as<float>(), m,
+                               dots, dots_stride, n_rowblk, n_colblk);
+        }
         CSLAM_HIP_TRY(hipGetLastError());
         if (prof) {
             CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
@@ -1699,11 +1988,12 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
                                       out_sim, st);
     }
     int64_t sims_stride = (p->vn + 63) / 64 * 64;
-    int64_t chunk = m < kQueryChunk ? m : kQueryChunk;
+    const int64_t qc = query_chunk(sims_stride);
+    int64_t chunk = m < qc ? m : qc;
     CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
     float* sims = p->sims.as<float>();
-    for (int q0 = 0; q0 < m; q0 += (int)kQueryChunk) {
-        int mb = m - q0 < (int)kQueryChunk ? m - q0 : (int)kQueryChunk;
+    for (int q0 = 0; q0 < m; q0 += (int)qc) {
+        int mb = m - q0 < (int)qc ? m - q0 : (int)qc;
         CSLAM_TRY(compute_dots(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,
                                st));
         if (k <= kSelectMaxK)

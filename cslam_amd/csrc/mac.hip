@@ -33,6 +33,7 @@
 // exact top-k, duality gap, step — without a host round trip; stop flag and errors are sticky
 // words on the device that turn the rest of the queue into no-ops.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(kScanThreads) void k_update_fwd_agg(
 // broadcast.  Partition: workgroup b owns nodes [b*512*E, (b+1)*512*E), thread t the E
 // consecutive nodes from (b*512 + t)*E.
 // Exit: all workgroups leave on the same iteration (converged / max_iters / NaN).  A poll that
-// is not satisfied within kSpinCap reads (the CUs are held by someone else's kernel) ends the
+// is not satisfied within g_spin_cap reads (the CUs are held by someone else's kernel) ends the
 // workgroup with done = 4; the others then time out too, and the host redoes the solve with
 // the graph-captured launches from the same x.
 // --------------------------------------------------------------------------------------------
@@ -1032,7 +1033,13 @@ constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
 constexpr int kPMaxElems = 8;
 constexpr int kPRowRegs = 3;     // adjacency entries of a row kept in registers
 constexpr int kPOverflow = 2;    // overflow-table entries a thread serves for its workgroup
-constexpr long kSpinCap = 1L << 20;
+constexpr long kSpinCapDefault = 1L << 20;
+// consulted only by a poll that has already spun 64 times (a healthy round needs one or two
+// re-reads): the hot path never loads it.  CSLAM_MAC_SPIN_CAP overrides it (tests).
+__device__ long g_spin_cap = kSpinCapDefault;
+__device__ inline bool spin_expired(long spins) {
+    return spins > 64 && spins > *reinterpret_cast<volatile long*>(&g_spin_cap);
+}
 
 typedef double d2 __attribute__((ext_vector_type(2)));  // {value, stamp}
 
@@ -1047,6 +1054,7 @@ struct PArgs {
     Scalars* sc;
     int n;
     long long* prof;  // optional [16]: per-phase 100 MHz ticks of workgroup 0 (CSLAM_MAC_PROF)
+    int inject_timeout;  // tests only (CSLAM_MAC_INJECT_TIMEOUT): the last workgroup never publishes
 };
 
 // slot offsets inside the exchange buffer; every array is [2 parities][...]
@@ -1075,7 +1083,7 @@ __device__ inline void st_slot(SlotBuf rs, int slot, double v, double stamp) {
 __device__ inline double poll_slot(SlotBuf rs, int slot, d2 v, double stamp, int& ok) {
     long spins = 0;
     while (v.y != stamp) {
-        if (++spins > kSpinCap) {
+        if (spin_expired(++spins)) {
             ok = 0;
             break;
         }
@@ -1090,7 +1098,7 @@ __device__ inline void poll_slots2(SlotBuf rs, int s0, int s1, bool use1, d2& v0
                                    int& ok) {
     long spins = 0;
     while (v0.y != stamp || (use1 && v1.y != stamp)) {
-        if (++spins > kSpinCap) {
+        if (spin_expired(++spins)) {
             ok = 0;
             break;
         }
@@ -1173,15 +1181,21 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     Scalars* sc = a.sc;
     // nothing to do (or nothing sane to do): an earlier solve of this asynchronous sequence
     // failed, the Frank-Wolfe loop has stopped, or the preconditioner has a pivot <= 0
-    if (sc->err || sc->fw_done || sc->factor_bad) {
-        if (b == 0 && tid == 0 && sc->factor_bad && !sc->err) {
+    // agent-scope (sc1) reads: a workgroup scheduled late must not see a stale copy of these
+    // words in its XCD's L2 (the previous solve's workgroup 0 wrote them from another XCD)
+    const int err0 = __hip_atomic_load(&sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err0 || sc->fw_done || sc->factor_bad) {
+        if (b == 0 && tid == 0 && sc->factor_bad && !err0) {
             sc->done = 5;
             sc->err = 5;
         }
         return;
     }
+    if (a.inject_timeout && b == nb - 1) return;  // fault injection: everybody else times out
     const SlotBuf xb = slot_buffer(a.xs, kSlotW + 2 * a.wstride);
-    const double stamp0 = a.ps->stamp_next;
+    const double stamp0 = __longlong_as_double((long long)__hip_atomic_load(
+        reinterpret_cast<unsigned long long*>(&a.ps->stamp_next), __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT));
     const double lnorm = __longlong_as_double((long long)sc->lnorm_bits);
     const double tol = sc->tol;
     const int max_iters = sc->max_iters;
@@ -1527,7 +1541,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
 #pragma unroll
                     for (int j = 0; j < kPOverflow; ++j) stale |= h_on[j] && gh[j].y != stamp;
                     if (!stale) break;
-                    if (++spins > kSpinCap) {
+                    if (spin_expired(++spins)) {
                         ok = 0;
                         break;
                     }
@@ -1589,7 +1603,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) stale |= base + t < cn[e] && gx[t].y != stamp;
                         if (!stale) break;
-                        if (++spins > kSpinCap) {
+                        if (spin_expired(++spins)) {
                             ok = 0;
                             break;
                         }
@@ -2081,12 +2095,14 @@ struct cslam_mac {
     int64_t wstride = 0;
     PersistState* pstate = nullptr;  // device: next stamp (slots start zeroed; stamps only grow)
     double* trace_d = nullptr;       // lambda_2 per Frank-Wolfe iteration (asynchronous loop)
+    void* arena = nullptr;           // ONE device allocation behind every buffer of mac_create
     int trace_cap = 0;
     double* dual_part = nullptr;     // per-block partials of the duality-gap dot product
     long long* prof = nullptr;
     int persist_elems = 0;    // nodes per thread of the persistent solver (0 = graph path)
     int persist_blocks = 0;
     int64_t persist_fallbacks = 0;
+    int inject_timeouts = 0;     // CSLAM_MAC_INJECT_TIMEOUT: sabotage this many persistent solves
     double *wvec = nullptr, *gvec = nullptr, *svec = nullptr;  // FW state [m]
     TopkState* tk_state = nullptr;
     unsigned int* tk_hist = nullptr;
@@ -2108,6 +2124,24 @@ int dev_alloc(T** p, size_t count) {
     CSLAM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (count > 0 ? count : 1) * sizeof(T)));
     return CSLAM_OK;
 }
+
+// mac_create needs ~45 device buffers; one hipMalloc (and one hipFree) instead of 45 of each
+// takes ~3 ms off every select_candidates call (a MAC handle lives for one selection).
+struct DeviceArena {
+    std::vector<std::pair<void**, size_t>> wants;  // (where the pointer goes, byte offset)
+    size_t total = 0;
+    template <class T>
+    int want(T** p, size_t count) {
+        wants.emplace_back(reinterpret_cast<void**>(p), total);
+        total += ((count > 0 ? count : 1) * sizeof(T) + 255) / 256 * 256;
+        return CSLAM_OK;
+    }
+    int commit(void** base) {
+        CSLAM_HIP_TRY(hipMalloc(base, total));
+        for (auto& w : wants) *w.first = static_cast<char*>(*base) + w.second;
+        return CSLAM_OK;
+    }
+};
 
 struct UnionFind {
     std::vector<int32_t> parent;
@@ -2243,6 +2277,11 @@ void enqueue_persistent(cslam_mac* mac) {
     pa.sc = mac->sc;
     pa.n = mac->n;
     pa.prof = mac->prof;
+    pa.inject_timeout = 0;
+    if (mac->inject_timeouts > 0) {
+        pa.inject_timeout = 1;
+        mac->inject_timeouts--;
+    }
     const dim3 grid((unsigned)mac->persist_blocks), block(kPT);
     hipStream_t st = mac->stream;
     switch (mac->persist_elems) {
@@ -2313,6 +2352,22 @@ int clear_sticky_error(cslam_mac* mac) {
     return CSLAM_OK;
 }
 
+// After a timed-out exchange round some workgroups may still have published slots carrying
+// stamps of the abandoned solve, and a late one may have read an already advanced stamp_next:
+// wipe every slot and move the stamp far ahead, so nothing the next persistent solve polls for
+// can already be there.
+int recover_persistent_timeout(cslam_mac* mac) {
+    hipStream_t st = mac->stream;
+    PersistState ps{};
+    CSLAM_HIP_TRY(hipMemcpyAsync(&ps, mac->pstate, sizeof(ps), hipMemcpyDeviceToHost, st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    ps.stamp_next += 1048576.0;
+    CSLAM_HIP_TRY(hipMemcpyAsync(mac->pstate, &ps, sizeof(ps), hipMemcpyHostToDevice, st));
+    CSLAM_HIP_TRY(hipMemsetAsync(mac->xslots, 0, (size_t)(kSlotW + 2 * mac->wstride) * sizeof(d2), st));
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    return CSLAM_OK;
+}
+
 void note_persistent_fallback(cslam_mac* mac) {
     if (mac->persist_fallbacks++ == 0)
         fprintf(stderr,
@@ -2334,7 +2389,12 @@ int fiedler_device(cslam_mac* mac, double tol_abi, int32_t* iters_out) {
             // an exchange round was not met in time (the CUs were held by someone else's
             // kernel): x is untouched, iterate with ordinary launches instead
             note_persistent_fallback(mac);
+            CSLAM_TRY(recover_persistent_timeout(mac));
             CSLAM_TRY(clear_sticky_error(mac));
+            // the timed-out kernel left done = 4 behind: the graph path polls that very word
+            const int zero = 0;
+            CSLAM_HIP_TRY(hipMemcpyAsync(&mac->sc->done, &zero, sizeof(int), hipMemcpyHostToDevice,
+                                         mac->stream));
         } else {
             solved = true;
         }
@@ -2410,6 +2470,16 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     if (device_id < 0 || device_id >= ndev) return fail(CSLAM_E_INVALID, "mac_create: bad device");
     CSLAM_HIP_TRY(hipSetDevice(device_id));
 
+    const bool cprof = getenv("CSLAM_MAC_CREATE_PROF") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = tnow();
+    auto mark = [&](const char* what) {
+        if (cprof) {
+            const double t = tnow();
+            fprintf(stderr, "[cslam mac_create] %-22s %.3f ms\n", what, t - tmark);
+            tmark = t;
+        }
+    };
     cslam_mac* mac = new cslam_mac();
     mac->device = device_id;
     mac->n = num_poses;
@@ -2421,7 +2491,9 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     mac->ci.assign(cand_i, cand_i + n_cand);
     mac->cj.assign(cand_j, cand_j + n_cand);
     mac->cw.assign(cand_w, cand_w + n_cand);
+    mark("copy edge lists");
     mac->fixed_connected = graph_connected(mac, nullptr, 0.0);
+    mark("connectivity");
 
     const int n = mac->n;
     const int64_t E = n_fixed + n_cand;
@@ -2453,6 +2525,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
         int i = fixed_i[e], j = fixed_j[e];
         if (std::abs(i - j) == 1 && fixed_w[e] > 0.0) link[std::min(i, j)] = 1;
     }
+    mark("adjacency");
     mac->nscan = (n + kScanBlock - 1) / kScanBlock;
     mac->nfact = (n + kFactBlock - 1) / kFactBlock;
     mac->nred = std::min(kRedBlocksMax, (n + 255) / 256);
@@ -2477,6 +2550,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
         }
         if (const char* ev = getenv("CSLAM_MAC_PERSISTENT"))
             if (atoi(ev) == 0) mac->persist_elems = 0;
+        if (const char* ev = getenv("CSLAM_MAC_INJECT_TIMEOUT")) mac->inject_timeouts = atoi(ev);
     }
 
     int rc = CSLAM_OK;
@@ -2488,49 +2562,57 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
         delete mac;
         return fail(CSLAM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
     }
-    A(dev_alloc(&mac->adj_ptr, n + 1));
-    A(dev_alloc(&mac->adj_nbr, nbr.size()));
-    A(dev_alloc(&mac->adj_eid, eid.size()));
-    A(dev_alloc(&mac->ci_d, n_cand));
-    A(dev_alloc(&mac->cj_d, n_cand));
-    A(dev_alloc(&mac->cw_d, n_cand));
-    A(dev_alloc(&mac->ew, E));
+    DeviceArena arena;
+    A(arena.want(&mac->adj_ptr, n + 1));
+    A(arena.want(&mac->adj_nbr, nbr.size()));
+    A(arena.want(&mac->adj_eid, eid.size()));
+    A(arena.want(&mac->ci_d, n_cand));
+    A(arena.want(&mac->cj_d, n_cand));
+    A(arena.want(&mac->cw_d, n_cand));
+    A(arena.want(&mac->ew, E));
     mac->nslot = (int64_t)nbr.size();
-    A(dev_alloc(&mac->aw, nbr.size()));
-    A(dev_alloc(&mac->cnbr, nbr.size()));
-    A(dev_alloc(&mac->cnt, n));
-    A(dev_alloc(&mac->pub, n));
-    A(dev_alloc(&mac->chl, n));
-    A(dev_alloc(&mac->chr, n));
-    A(dev_alloc(&mac->link, n));
+    A(arena.want(&mac->aw, nbr.size()));
+    A(arena.want(&mac->cnbr, nbr.size()));
+    A(arena.want(&mac->cnt, n));
+    A(arena.want(&mac->pub, n));
+    A(arena.want(&mac->chl, n));
+    A(arena.want(&mac->chr, n));
+    A(arena.want(&mac->link, n));
     for (double** v : {&mac->a, &mac->b, &mac->l, &mac->invd, &mac->x, &mac->w, &mac->p, &mac->Ax,
                        &mac->Aw, &mac->Ap, &mac->r, &mac->y})
-        A(dev_alloc(v, n));
-    A(dev_alloc(&mac->agg_f, mac->nscan));
-    A(dev_alloc(&mac->agg_b, mac->nscan));
-    A(dev_alloc(&mac->agg_m, mac->nfact));
-    A(dev_alloc(&mac->psum, mac->nscan));
-    A(dev_alloc(&mac->partial, (size_t)npartial * 12));
-    A(dev_alloc(&mac->rpart, std::max(mac->nred, mac->nscan)));
-    A(dev_alloc(&mac->sc, 1));
-    A(dev_alloc(&mac->pstate, 1));
-    A(dev_alloc(&mac->dual_part, (size_t)((n_cand + 255) / 256)));
+        A(arena.want(v, n));
+    A(arena.want(&mac->agg_f, mac->nscan));
+    A(arena.want(&mac->agg_b, mac->nscan));
+    A(arena.want(&mac->agg_m, mac->nfact));
+    A(arena.want(&mac->psum, mac->nscan));
+    A(arena.want(&mac->partial, (size_t)npartial * 12));
+    A(arena.want(&mac->rpart, std::max(mac->nred, mac->nscan)));
+    A(arena.want(&mac->sc, 1));
+    A(arena.want(&mac->pstate, 1));
+    A(arena.want(&mac->dual_part, (size_t)((n_cand + 255) / 256)));
     mac->wstride = ((int64_t)n + 63) / 64 * 64;
     const size_t nslots = (size_t)(kSlotW + 2 * mac->wstride);
-    A(dev_alloc(&mac->xslots, nslots));
-    if (mac->xslots && hipMemset(mac->xslots, 0, nslots * sizeof(d2)) != hipSuccess)
-        A(fail(CSLAM_E_HIP, "mac_create: memset failed"));
-    if (getenv("CSLAM_MAC_PROF")) {
-        A(dev_alloc(&mac->prof, 16 + 128));
-        if (mac->prof) (void)hipMemset(mac->prof, 0, (16 + 128) * sizeof(long long));
+    A(arena.want(&mac->xslots, nslots));
+    if (getenv("CSLAM_MAC_PROF")) A(arena.want(&mac->prof, 16 + 128));
+    A(arena.want(&mac->wvec, n_cand));
+    A(arena.want(&mac->gvec, n_cand));
+    A(arena.want(&mac->svec, n_cand));
+    A(arena.want(&mac->tk_state, 1));
+    A(arena.want(&mac->tk_hist, kTopkBins));
+    A(arena.want(&mac->tk_lkey, kTopkListCap));
+    A(arena.want(&mac->tk_lidx, kTopkListCap));
+    mark("stream");
+    A(arena.commit(&mac->arena));
+    mark("device arena");
+    if (const char* ev = getenv("CSLAM_MAC_SPIN_CAP")) {
+        const long cap = atol(ev);
+        if (rc == CSLAM_OK && cap > 0 &&
+            hipMemcpyToSymbol(HIP_SYMBOL(g_spin_cap), &cap, sizeof(cap)) != hipSuccess)
+            A(fail(CSLAM_E_HIP, "mac_create: spin cap upload failed"));
     }
-    A(dev_alloc(&mac->wvec, n_cand));
-    A(dev_alloc(&mac->gvec, n_cand));
-    A(dev_alloc(&mac->svec, n_cand));
-    A(dev_alloc(&mac->tk_state, 1));
-    A(dev_alloc(&mac->tk_hist, kTopkBins));
-    A(dev_alloc(&mac->tk_lkey, kTopkListCap));
-    A(dev_alloc(&mac->tk_lidx, kTopkListCap));
+    if (rc == CSLAM_OK && hipMemset(mac->xslots, 0, nslots * sizeof(d2)) != hipSuccess)
+        A(fail(CSLAM_E_HIP, "mac_create: memset failed"));
+    if (rc == CSLAM_OK && mac->prof) (void)hipMemset(mac->prof, 0, (16 + 128) * sizeof(long long));
     if (rc != CSLAM_OK) {
         cslam_mac_destroy(mac);
         return rc;
@@ -2552,6 +2634,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
     H2D(mac->x, x0.data(), (size_t)n * 8);
     const PersistState ps0{1.0};
     H2D(mac->pstate, &ps0, sizeof(ps0));
+    mark("uploads");
     if (rc == CSLAM_OK && (hipMemset(mac->sc, 0, sizeof(Scalars)) != hipSuccess ||
                            hipMemset(mac->l, 0, sizeof(double) * n) != hipSuccess ||
                            hipMemset(mac->tk_hist, 0, sizeof(unsigned int) * kTopkBins) != hipSuccess ||
@@ -2563,6 +2646,7 @@ int cslam_mac_create(int32_t num_poses, const int32_t* fixed_i, const int32_t* f
                            // ordered against the null stream): finish them before any solve
                            hipStreamSynchronize(nullptr) != hipSuccess))
         rc = fail(CSLAM_E_HIP, "mac_create: init failed");
+    mark("memsets + events");
     if (rc != CSLAM_OK) {
         cslam_mac_destroy(mac);
         return rc;
@@ -2594,18 +2678,8 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
         }
     }
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
-    for (void* p : {(void*)mac->adj_ptr, (void*)mac->adj_nbr, (void*)mac->adj_eid, (void*)mac->ci_d,
-                    (void*)mac->cj_d, (void*)mac->cw_d, (void*)mac->ew, (void*)mac->aw, (void*)mac->cnbr, (void*)mac->cnt, (void*)mac->pub, (void*)mac->chl, (void*)mac->chr,
-                    (void*)mac->link,
-                    (void*)mac->a, (void*)mac->b,
-                    (void*)mac->l, (void*)mac->invd, (void*)mac->x, (void*)mac->w, (void*)mac->p,
-                    (void*)mac->Ax, (void*)mac->Aw, (void*)mac->Ap, (void*)mac->r, (void*)mac->y,
-                    (void*)mac->agg_f, (void*)mac->agg_b, (void*)mac->agg_m, (void*)mac->psum, (void*)mac->partial,
-                    (void*)mac->rpart, (void*)mac->sc, (void*)mac->pstate, (void*)mac->dual_part,
-                    (void*)mac->trace_d, (void*)mac->xslots, (void*)mac->prof, (void*)mac->wvec, (void*)mac->gvec,
-                    (void*)mac->svec, (void*)mac->tk_state, (void*)mac->tk_hist, (void*)mac->tk_lkey,
-                    (void*)mac->tk_lidx})
-        if (p) (void)hipFree(p);
+    if (mac->arena) (void)hipFree(mac->arena);       // every buffer of mac_create lives in it
+    if (mac->trace_d) (void)hipFree(mac->trace_d);   // sized by the first fw_subset call
     if (mac->ev0) (void)hipEventDestroy(mac->ev0);
     if (mac->ev1) (void)hipEventDestroy(mac->ev1);
     if (mac->stream) (void)hipStreamDestroy(mac->stream);
@@ -2854,6 +2928,7 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
             // an exchange round of the persistent solver timed out: redo the selection with
             // host-paced launches, from the caller's w and a fresh start vector
             note_persistent_fallback(mac);
+            CSLAM_TRY(recover_persistent_timeout(mac));
             reset_start_vector();
             std::memset(&h, 0, sizeof(h));
             h.fw_u = INFINITY;

@@ -122,3 +122,34 @@ def test_budget_clamp_and_empty():
     # robot 1 out of range: nothing to select
     acm.add_match(EdgeInterRobot(0, 3, 1, 4, 0.9))
     assert acm.select_candidates(1, {0: True, 1: False}) == []
+
+
+def test_candidate_store_is_a_dict_that_keeps_its_rows_in_dict_order():
+    """`candidate_edges` keeps a float64 row per candidate in dict order (what select_candidates
+    reads at 200k-candidate scale): random inserts / overwrites / removals / re-inserts against
+    a plain dict."""
+    import random
+    from cslam_amd.algebraic_connectivity_maximization import _CandidateStore
+    rs = random.Random(3)
+    plain, store = {}, _CandidateStore()
+    for _ in range(30000):
+        op = rs.random()
+        key = (0, rs.randrange(200), 1, rs.randrange(20))
+        if op < 0.55:
+            e = EdgeInterRobot(key[0], key[1], key[2], key[3], rs.random())
+            plain[key] = e
+            store[key] = e
+        elif op < 0.9:
+            assert plain.pop(key, None) == store.pop(key, None)
+        elif plain:
+            k2 = next(iter(plain))
+            del plain[k2]
+            del store[k2]
+    assert list(plain) == list(store) and plain == dict(store)
+    np.testing.assert_array_equal(store.live_rows(),
+                                  np.array([list(v) for v in plain.values()]).reshape(-1, 5))
+    acm = AlgebraicConnectivityMaximization(0, 2)
+    acm.candidate_edges = dict(plain)                 # plain-dict assignment is adopted
+    np.testing.assert_array_equal(acm.candidate_edges.live_rows(), store.live_rows())
+    store.clear()
+    assert len(store) == 0 and store.live_rows().shape == (0, 5)

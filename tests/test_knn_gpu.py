@@ -38,7 +38,8 @@ def _check(gpu, X, Q, k):
     (5000, 4096, 16, 10),     # cfg2 row shape
     (3000, 4096, 33, 1),      # T=4 scan
     (3000, 256, 20, 3),       # T=2 scan
-    (9000, 48, 300, 64),      # query chunking (> 256 queries), k = 64
+    (9000, 48, 300, 64),      # three GEMM tiles in one chunk, k = 64
+    (2000, 64, 1100, 3),      # query chunking (> 1024 queries per call)
     (600, 33, 2, 200),        # bitonic path, ragged dim
     (2000, 4096, 130, 10),    # LDS-tiled 32x32x2 GEMM path (>= 96 queries), ragged row/query tiles
     (777, 100, 256, 5),       # GEMM path, ragged dim, full 256-query chunk

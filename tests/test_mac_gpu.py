@@ -408,3 +408,54 @@ def test_graph_captured_solver_path_matches_reference(gpu, case, monkeypatch):
     assert abs(lam2 - (2 - np.sqrt(2))) < 1e-9
     m2.close()
     mac.close()
+
+
+def test_persistent_solver_timeout_recovery(gpu):
+    """The persistent LOBPCG kernel assumes its workgroups are co-resident; an exchange round
+    that is not met within the spin cap ends the solve with `done = 4` and the host redoes it
+    with graph-captured launches, wipes the exchange slots and moves the stamp far ahead.
+    Forced here by fault injection (CSLAM_MAC_INJECT_TIMEOUT: the last workgroup never
+    publishes) with a small spin cap, in a subprocess (both knobs are read at handle creation):
+    the sabotaged Fiedler solve, the persistent solve right after it, a sabotaged Frank-Wolfe
+    selection and the one after it all reproduce the goldens."""
+    import subprocess
+    import sys
+    case = [c for c in CASES if int(G[f"{c}_nb"][4]) >= 2000][-1]      # several workgroups
+    code = f"""
+import io, json, sys, numpy as np
+from contextlib import redirect_stdout
+sys.path.insert(0, '.')
+from cslam_amd.mac.mac import MAC
+from cslam_amd.mac.utils import Edge
+G = np.load('tests/golden/mac_ref.npz'); c = '{case}'
+g = lambda s: G[c + '_' + s]
+fixed = [Edge(int(i), int(j), float(w)) for i, j, w in zip(g('fi'), g('fj'), g('fw'))]
+cand = [Edge(int(i), int(j), float(w)) for i, j, w in zip(g('ci'), g('cj'), g('cw'))]
+out = {{}}
+mac = MAC(fixed, cand, int(g('nb')[4]))            # INJECT_TIMEOUT=1: first persistent launch
+out['lam_sabotaged'] = mac.evaluate_fiedler_pair(g('w_init'))[0]
+out['lam_after'] = mac.evaluate_fiedler_pair(g('w_last'))[0]
+out['lam_again'] = mac.evaluate_fiedler_pair(g('w_init'))[0]
+mac.close()
+mac = MAC(fixed, cand, int(g('nb')[4]))            # first launch of the queued FW loop sabotaged
+with redirect_stdout(io.StringIO()):
+    r1 = mac.fw_subset(g('w_init'), int(g('nb')[3]), max_iters=20)[0]
+    r2 = mac.fw_subset(g('w_init'), int(g('nb')[3]), max_iters=20)[0]
+out['trace2'] = [float(x) for x in mac.lambda_trace]
+mac.close()
+out['r1'] = [int(x) for x in np.nonzero(r1)[0]]; out['r2'] = [int(x) for x in np.nonzero(r2)[0]]
+print(json.dumps(out))
+"""
+    env = dict(os.environ, CSLAM_MAC_SPIN_CAP="20000", CSLAM_MAC_INJECT_TIMEOUT="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         cwd=os.path.dirname(HERE), timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "timed out" in res.stderr                    # the fallback really ran
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    g = lambda s: G[f"{case}_{s}"]
+    assert abs(out["lam_sabotaged"] - g("lambda_trace")[0]) < 1e-9
+    assert abs(out["lam_after"] - g("lambda_trace")[-1]) < 1e-9
+    assert abs(out["lam_again"] - g("lambda_trace")[0]) < 1e-9
+    want = [int(x) for x in np.nonzero(g("rounded"))[0]]
+    assert out["r1"] == want and out["r2"] == want
+    np.testing.assert_allclose(out["trace2"], g("lambda_trace"), atol=1e-9)

@@ -251,7 +251,7 @@ def test_sharded_protocol_on_hip_pools_matches_sequential_reference(gpu):
         assert results[r] == results[0]
 
 
-def _sequential_reference_with(blocks, world, steps):
+def _sequential_reference_with(blocks, world, steps, thr=THR):
     from cslam_amd.algebraic_connectivity_maximization import (AlgebraicConnectivityMaximization,
                                                                EdgeInterRobot)
     local = [OracleMatcher() for _ in range(world)]
@@ -273,7 +273,7 @@ def _sequential_reference_with(blocks, world, steps):
                 for i, kf in enumerate(kfs):
                     mirror[s][r].add_rows(torch.from_numpy(x[i:i + 1]), [kf])
                     kb, sim = best(local[s], x[i])
-                    if kb is not None and sim >= THR:
+                    if kb is not None and sim >= thr:
                         sel[s].add_match(EdgeInterRobot(s, kb, r, kf, sim))
         for r in range(world):
             x, kfs = blocks[(t, r)]
@@ -283,7 +283,7 @@ def _sequential_reference_with(blocks, world, steps):
                     if s == r:
                         continue
                     kb, sim = best(mirror[r][s], x[i])
-                    if kb is not None and sim >= THR:
+                    if kb is not None and sim >= thr:
                         sel[r].add_match(EdgeInterRobot(r, kf, s, kb, sim))
     union = {}
     for r in range(world):

@@ -181,6 +181,26 @@ def test_device_shard_bulk_blocks(gpu):
         assert local[r] == []                      # intra-robot matching is a fused-mode feature
 
 
+def test_device_shard_bulk_thousands_of_descriptors_per_step(gpu):
+    """cfg4's bulk case in miniature: blocks of ~2000 descriptors per rank and step (chunked
+    searches of 256 queries, GEMM-tile dots path), two ranks, against the sequential reference."""
+    world, steps, maxb = 2, 2, 2048
+    rs = np.random.RandomState(4)
+    blocks, nxt = {}, [0] * world
+    for t in range(steps):
+        for r in range(world):
+            b = int(rs.randint(1500, maxb + 1))
+            blocks[(t, r)] = (rs.rand(b, DIM).astype(np.float32), list(range(nxt[r], nxt[r] + b)))
+            nxt[r] += b
+    results, _, _ = _run_shards(world, steps, blocks, maxb, 10, 5, thr=0.8)
+    union, _ = _sequential_reference_with(blocks, world, steps, thr=0.8)
+    assert len(union) > 200
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for key in union:
+            assert abs(results[r][key] - union[key]) <= 1e-7
+
+
 def test_device_shard_single_robot_and_pipelining(gpu):
     """One robot, no communicator: nothing to match against, blocks are appended; up to four steps
     may be in flight, a fifth publish without a fetch is refused loudly."""

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 from cslam_amd import _lib
 from cslam_amd.nns_matching import NearestNeighborsMatching
 import torch
-L = _lib.load(); N, D, M = 100000, 4096, 256
+L = _lib.load(); N, D, M = 100000, 4096, 1024
 g = torch.Generator(device="cuda").manual_seed(0)
 X = torch.rand((N, D), device="cuda", generator=g)
 m = NearestNeighborsMatching(dim=D, capacity_hint=N)
