@@ -50,14 +50,15 @@ class EdgeInterRobot(NamedTuple):
 
 class _CandidateStore(dict):
     """`candidate_edges` — a dict keyed by the normalised edge key like the reference's
-    (acm.py:45), which ALSO keeps the (r0, kf0, r1, kf1, weight) rows in one float64 array in
-    dict order: a slot per key (overwriting keeps the slot, like a dict keeps the position of
-    an existing key; a re-inserted key goes to the end in both).  `select_candidates` at cfg3
-    scale (200k candidates) reads `live_rows()` instead of walking 200k Python objects."""
+    (acm.py:45), which ALSO keeps (r0, kf0, r1, kf1) as int64 columns and the weight as a float64
+    column in dict order: a slot per key (overwriting keeps the slot, like a dict keeps the
+    position of an existing key; a re-inserted key goes to the end in both).  `select_candidates`
+    at cfg3 scale (200k candidates) reads `live_columns()` instead of walking 200k Python objects."""
 
     def __init__(self, *args, **kwargs):
         super().__init__()
-        self._rows = np.empty((1024, 5), dtype=np.float64)
+        self._ids = np.empty((4, 1024), dtype=np.int64)
+        self._w = np.empty(1024, dtype=np.float64)
         self._alive = np.zeros(1024, dtype=bool)
         self._slot = {}
         self._n = 0
@@ -66,15 +67,18 @@ class _CandidateStore(dict):
 
     def _grow(self):
         cap = 2 * len(self._alive)
-        rows = np.empty((cap, 5), dtype=np.float64)
-        rows[:self._n] = self._rows[:self._n]
+        ids = np.empty((4, cap), dtype=np.int64)
+        ids[:, :self._n] = self._ids[:, :self._n]
+        w = np.empty(cap, dtype=np.float64)
+        w[:self._n] = self._w[:self._n]
         alive = np.zeros(cap, dtype=bool)
         alive[:self._n] = self._alive[:self._n]
-        self._rows, self._alive = rows, alive
+        self._ids, self._w, self._alive = ids, w, alive
 
     def _compact(self):
-        keep = np.nonzero(self._alive[:self._n])[0]
-        self._rows[:len(keep)] = self._rows[keep]
+        keep = np.flatnonzero(self._alive[:self._n])
+        self._ids[:, :len(keep)] = self._ids[:, keep]
+        self._w[:len(keep)] = self._w[keep]
         self._alive[:len(keep)] = True
         self._alive[len(keep):self._n] = False
         self._n = len(keep)
@@ -92,7 +96,8 @@ class _CandidateStore(dict):
             self._n += 1
             self._slot[key] = s
             self._alive[s] = True
-        self._rows[s] = edge
+        self._ids[:, s] = edge[:4]
+        self._w[s] = edge[4]
         super().__setitem__(key, edge)
 
     def __delitem__(self, key):
@@ -129,9 +134,20 @@ class _CandidateStore(dict):
             self[key] = default
         return self[key]
 
+    def live_columns(self):
+        """(r0, kf0, r1, kf1 as int64, weight as float64), each of len(self), in dict order
+        (views of the store while nothing has been removed, compacted copies otherwise)."""
+        n = self._n
+        if len(self) == n:
+            return (self._ids[0, :n], self._ids[1, :n], self._ids[2, :n], self._ids[3, :n],
+                    self._w[:n])
+        alive = self._alive[:n]
+        return tuple(self._ids[c, :n][alive] for c in range(4)) + (self._w[:n][alive],)
+
     def live_rows(self):
         """float64 [len(self), 5] in dict order."""
-        return self._rows[:self._n][self._alive[:self._n]]
+        return np.stack([c.astype(np.float64) for c in self.live_columns()], axis=1) \
+            if len(self) else np.zeros((0, 5))
 
 
 class AlgebraicConnectivityMaximization(object):
@@ -437,33 +453,30 @@ class AlgebraicConnectivityMaximization(object):
                 or not self.params["frontend.enable_sparsification"]:
             return None
         nr = self.max_nb_robots
-        cand = self.candidate_edges.live_rows()
+        c_r0, c_k0, c_r1, c_k1, c_w = self.candidate_edges.live_columns()
         fixed = self._inter_robot_rows(self.fixed_edges, len(self.fixed_edges))
+        f_r0, f_k0, f_r1, f_k1 = (fixed[:, c].astype(np.int64) for c in range(4))
         considered = np.array([bool(is_other_robot_considered[r]) for r in range(nr)])
         # check_graph_disconnections (acm.py:390-416)
-        included = np.zeros(nr, dtype=bool)
+        seen = np.zeros(nr, dtype=bool)
+        for ids in (f_r0, f_r1, c_r0, c_r1):
+            seen[ids] = True
+        included = seen & considered
         included[self.robot_id] = True
-        for rows in (fixed, cand):
-            for col in (0, 2):
-                ids = rows[:, col].astype(np.int64)
-                seen = np.zeros(nr, dtype=bool)
-                seen[np.unique(ids)] = True
-                included |= seen & considered
         is_robot_included = {r: bool(included[r]) for r in range(nr)}
         if not self.check_initial_fixed_measurements_exists(is_robot_included):
             return None  # connection-biased greedy branch: list path
         self.compute_offsets(is_robot_included)
         off = np.array([self.offsets[r] for r in range(nr)], dtype=np.int64)
 
-        def rekey(rows):
-            r0, r1 = rows[:, 0].astype(np.int64), rows[:, 2].astype(np.int64)
-            keep = included[r0] & included[r1]
-            r0, r1 = r0[keep], r1[keep]
-            return (off[r0] + rows[keep, 1].astype(np.int64), off[r1] + rows[keep, 3].astype(np.int64),
-                    rows[keep, 4])
+        def rekey(r0, k0, r1, k1, w):
+            if not included[seen].all():             # some edge touches an excluded robot
+                keep = included[r0] & included[r1]
+                r0, k0, r1, k1, w = r0[keep], k0[keep], r1[keep], k1[keep], w[keep]
+            return off[r0] + k0, off[r1] + k1, w
 
-        fi, fj, fw = rekey(fixed)
-        ci, cj, cw = rekey(cand)
+        fi, fj, fw = rekey(f_r0, f_k0, f_r1, f_k1, fixed[:, 4])
+        ci, cj, cw = rekey(c_r0, c_k0, c_r1, c_k1, c_w)
         # fill_odometry (acm.py:347-361): EVERY known robot, included or not
         oi = [np.arange(self.offsets[r], self.offsets[r] + max(self.nb_poses[r] - 1, 0), dtype=np.int64)
               for r in range(len(self.nb_poses))]
