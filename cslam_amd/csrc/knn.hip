@@ -1367,11 +1367,14 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
         v[e] = c;
     }
 
-    for (int rd = 0; rd < k; ++rd) {
-        uint64_t m = v[0];
+    // every thread keeps the maximum of its 16 composites; a round only costs a block-wide
+    // maximum of those, and the ONE thread that owned the winner (composites are unique: the row
+    // is part of them) re-scans its 16 — the other three waves skip that altogether
+    uint64_t mt = v[0];
 #pragma unroll
-        for (int e = 1; e < 16; ++e) m = v[e] > m ? v[e] : m;
-        m = wave_max_u64(m);
+    for (int e = 1; e < 16; ++e) mt = v[e] > mt ? v[e] : mt;
+    for (int rd = 0; rd < k; ++rd) {
+        const uint64_t m = wave_max_u64(mt);
         if (lane == 0) wmax[rd & 1][wave] = m;
         __syncthreads();
         uint64_t win = wmax[rd & 1][0];
@@ -1380,10 +1383,13 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ sims,
             uint64_t o = wmax[rd & 1][x];
             win = o > win ? o : win;
         }
-        if (win != 0) {
+        if (win != 0 && mt == win) {
+            mt = 0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
+            for (int e = 0; e < 16; ++e) {
                 if (v[e] == win) v[e] = 0;
+                mt = v[e] > mt ? v[e] : mt;
+            }
         }
         if (tid == 0) {
             if (FINAL) {
