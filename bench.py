@@ -79,14 +79,37 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+    # rank 0's stdout is drained by a thread; the parent watches all ranks so that one that
+    # dies (a rank that cannot get its GPU, say) takes the others down instead of leaving them
+    # waiting in the rendezvous for ever — only the exact processes started here are signalled
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
     if out0:
         sys.stdout.write(out0)
         sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+    if failed:
+        sys.stderr.write(f"bench.py: rank(s) failed: {failed}\n")
         return 1
     return 0
 
@@ -219,7 +242,10 @@ def main():
         step(t)
     drain()
     fence()
-    _lib.check(L.cslam_pool_profile_begin(pool.handle, args.steps))
+    # HIP events around every 4th scan launch of the timed region (a pair costs ~8 us of stream
+    # time, tools/event_cost.py: bracketing every launch would tax the very step being timed)
+    prof_every = 4 if args.steps >= 8 else 1
+    _lib.check(L.cslam_pool_profile_begin_sampled(pool.handle, args.steps, prof_every))
     bytes0 = 0
     if world > 1:
         state["records"] = 0
@@ -300,7 +326,8 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_of_measured_copy_peak": achieved / 6290.0,
                      "traffic": traffic, "avg_kernel_ms": scan_ms.value,
-                     "launches_timed": n_l.value, "algorithmic_bytes_per_launch": alg_bytes},
+                     "launches_timed": n_l.value, "launches_sampled_every": prof_every,
+                     "algorithmic_bytes_per_launch": alg_bytes},
     }
     if dist_info:
         result["dist"] = dist_info

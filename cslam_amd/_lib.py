@@ -63,6 +63,7 @@ SIGNATURES = {
                                                _c.c_int64, _vp, _vp, _vp]),
     "cslam_pool_similarities_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int64, _vp]),
     "cslam_pool_profile_begin": (_c.c_int, [_vp, _c.c_int]),
+    "cslam_pool_profile_begin_sampled": (_c.c_int, [_vp, _c.c_int, _c.c_int]),
     "cslam_pool_profile_end": (_c.c_int, [_vp, _f64p, _c.POINTER(_c.c_int)]),
     "cslam_pool_scan_kernel": (_c.c_char_p, [_vp]),
     "cslam_comm_unique_id": (_c.c_int, [_vp]),

@@ -1484,6 +1484,7 @@ struct cslam_pool {
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
+    int prof_every = 1, prof_tick = 0;  // bracket every prof_every-th dots launch
     bool prof_on = false;
     const char* last_scan_kernel = "";  // variant of the last dots kernel launched (bench.py)
     // ordering between the device-pointer API (caller's stream) and the host-pointer API (the
@@ -1561,6 +1562,13 @@ void launch_scan_u(cslam_pool* p, const float* Q, int m_valid, float* dots, int6
         launch_scan_t<T, S, (UMAX >= 2 ? 2 : UMAX)>(p, Q, m_valid, dots, dots_stride, n_waves, st);
     else
         launch_scan_t<T, S, 1>(p, Q, m_valid, dots, dots_stride, n_waves, st);
+}
+
+// bracket this dots launch with HIP events?  (every prof_every-th one: an event pair costs ~8 us
+// of step time — tools/event_cost.py — so bench.py samples instead of bracketing every launch)
+bool prof_take(cslam_pool* p) {
+    if (!p->prof_on || p->prof_n >= p->prof_max) return false;
+    return (p->prof_tick++ % p->prof_every) == 0;
 }
 
 // does the DMA scan apply to the current row window?  (env: CSLAM_SCAN_KERNEL=ring|lds|pc keeps
@@ -1644,7 +1652,7 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     int64_t resident = (int64_t)p->cus * wpc;
     int64_t n_waves = groups < resident ? groups : resident;
     if (n_waves < 1) n_waves = 1;
-    bool prof = p->prof_on && p->prof_n < p->prof_max;
+    bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
     if (m <= 16) {
         static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
@@ -1783,7 +1791,7 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
                            m, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>(), vec_ok,
                            (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
-        bool prof = p->prof_on && p->prof_n < p->prof_max;
+        bool prof = prof_take(p);
         if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
         // CSLAM_GEMM=32 keeps the register-staged 128 x 128 kernel (A/B runs); the LDS-DMA kernel
         // needs dots rows it can store 16 bytes at a time (the sims workspace is 64-float aligned)
@@ -1981,7 +1989,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
         const int64_t cstride = ((int64_t)p->cus * 4 * ((p->vn + (int64_t)p->cus * 4 * 128 - 1) /
                                                         ((int64_t)p->cus * 4 * 128)) + 63) / 64 * 64;
         CSLAM_TRY(p->cand_a.reserve((size_t)16 * cstride * sizeof(uint64_t)));
-        bool prof = p->prof_on && p->prof_n < p->prof_max;
+        bool prof = prof_take(p);
         if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
         int64_t n_panels = 0;
         CSLAM_TRY(launch_scan_dma(p, qsrc, qs, q_rows, m, nullptr, 0, true,
@@ -2256,7 +2264,16 @@ int cslam_pool_profile_begin(cslam_pool_t* p, int max_launches) {
     }
     p->prof_max = max_launches;
     p->prof_n = 0;
+    p->prof_every = 1;
+    p->prof_tick = 0;
     p->prof_on = true;
+    return CSLAM_OK;
+}
+
+int cslam_pool_profile_begin_sampled(cslam_pool_t* p, int max_samples, int every) {
+    if (every < 1) return fail(CSLAM_E_INVALID, "profile_begin_sampled: every < 1");
+    CSLAM_TRY(cslam_pool_profile_begin(p, max_samples));
+    p->prof_every = every;
     return CSLAM_OK;
 }
 

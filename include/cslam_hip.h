@@ -101,6 +101,8 @@ int cslam_pool_similarities_dev(cslam_pool_t* pool, const float* queries_dev,
  * stream: average duration in ms of the last `n` scan-kernel launches recorded since
  * cslam_pool_profile_begin().  */
 int cslam_pool_profile_begin(cslam_pool_t* pool, int max_launches);
+/* same, bracketing only every `every`-th launch (an event pair costs ~8 us of stream time). */
+int cslam_pool_profile_begin_sampled(cslam_pool_t* pool, int max_samples, int every);
 int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launches);
 /* Name (static string) of the dot-product kernel variant the last search launched, e.g.
  * "k_scan_dma<NS=8,NW=4,NST=2,nt>": what the roofline line of bench.py is about. */
