@@ -193,6 +193,45 @@ def test_range_search_and_sharded_step_on_gpu(gpu):
     assert sh.matcher.size == 4
 
 
+def test_gemm_tail_tiles_and_range_search_on_a_large_pool(gpu):
+    """(a) 200 queries against 70 000 rows: 1094 GEMM tiles = two whole waves of 128 x 128 tiles
+    plus a remainder that runs as 64 x 128 tiles (k_gemm_dma<1,2>) — bit-exact against the oracle.
+    (b) the row-range search (what the sharded step uses) on a window large enough for the
+    LDS-DMA scan, with a non-zero first row: indices are absolute, similarities identical."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    from cslam_amd import _lib
+    rs = np.random.RandomState(12)
+    n, d = 70_000, 64
+    X = (rs.rand(n, d).astype(np.float32) - 0.4)
+    Q = rs.rand(200, d).astype(np.float32)
+    m = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = m.search_batch(Q, 3)
+    assert gpu.cslam_pool_scan_kernel(m.handle).decode().startswith("k_gemm_dma")
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 3)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    m.close()
+    # (b)
+    n, d, lo, hi = 40_000, 256, 7_001, 39_000
+    X = rs.rand(n, d).astype(np.float32)
+    Q = rs.rand(9, d).astype(np.float32)
+    m = _pool(gpu, X, dim=d, capacity_hint=n)
+    qd = torch.from_numpy(Q).cuda()
+    for k in (1, 4):
+        idx = torch.empty((9, k), dtype=torch.int32, device="cuda")
+        sim = torch.empty((9, k), dtype=torch.float32, device="cuda")
+        _lib.check(gpu.cslam_pool_search_range_dev(m.handle, ctypes.c_void_p(qd.data_ptr()), d, 9, k, lo, hi,
+                                                   ctypes.c_void_p(idx.data_ptr()),
+                                                   ctypes.c_void_p(sim.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert gpu.cslam_pool_scan_kernel(m.handle).decode().startswith("k_scan_dma")
+        o_idx, o_sim, _ = oracle_knn.search(X[lo:hi], Q, k)
+        np.testing.assert_array_equal(idx.cpu().numpy(), o_idx + lo)
+        assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
+    m.close()
+
+
 def test_search_best_device_queries_strided_and_unaligned(gpu):
     """search_best (k = 1) through the device-pointer ABI on the DMA path: a strided query
     view is read in place, a view that starts off a 16-byte boundary goes through the staging

@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 constexpr int kPieceB = 1024 + 32;       // bytes per row piece in LDS (256 floats + pad)
 constexpr int kStageB = 16 * kPieceB;    // one stage = 16 rows x 256 floats
@@ -26,8 +28,8 @@ __device__ inline void wait_vm_dyn(int n) {
         W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15)
         W(16) W(17) W(18) W(19) W(20) W(21) W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31)
         W(32) W(33) W(34) W(35) W(36) W(37) W(38) W(39) W(40) W(41) W(42) W(43) W(44) W(45) W(46) W(47)
-        W(48)
-        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        W(48) W(49) W(50) W(51) W(52) W(53) W(54) W(55) W(56) W(57) W(58) W(59) W(60) W(61) W(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
     }
 #undef W
 }
@@ -185,6 +187,174 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Piece-granular ring: the wave's LDS ring is RP one-row pieces (not whole stages); a stage's 16
+// slots are refilled with the next pieces in line as soon as it has been read, so RP-16 .. RP
+// KiB stay in flight per wave (stage ring of 2: 16 .. 32).
+// ---------------------------------------------------------------------------------------------
+template <int NS, int NW, int RP, int AUX>
+__global__ __launch_bounds__(NW * 64) void k_scan_pr(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
+                                                     const float* __restrict__ Q, float* __restrict__ dots,
+                                                     int64_t dots_stride, int n_panels, int ppw) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x * NW + wave;
+    char* ring = lds + wave * RP * kPieceB;
+    const int nkc = dp >> 8;
+    const int p_begin = w * ppw;
+    int p_end = p_begin + ppw;
+    if (p_end > n_panels) p_end = n_panels;
+    if (p_begin >= p_end) return;
+
+    auto panel = [&](Cursor& c, int p) {
+        c.p = p;
+        c.lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        c.rows = (int)(hi - c.lo);
+        c.ns = (c.rows + 15) >> 4;
+        c.kc = 0;
+        c.s = 0;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.s < c.ns) return;
+        c.s = 0;
+        if (++c.kc < nkc) return;
+        panel(c, c.p + 1);
+    };
+    auto count = [&](const Cursor& c) { int k = c.rows - 16 * c.s; return k > 16 ? 16 : k; };
+
+    int mark0 = 0, mark1 = 0, mark2 = 0, mark3 = 0;      // `issued` right after a stage's last piece
+    int start0 = 0, start1 = 0, start2 = 0, start3 = 0;  // ring position of a stage's first piece
+    auto set4 = [](int& a0, int& a1, int& a2, int& a3, int i, int v) {
+        a0 = i == 0 ? v : a0; a1 = i == 1 ? v : a1; a2 = i == 2 ? v : a2; a3 = i == 3 ? v : a3;
+    };
+    auto get4 = [](int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); };
+
+    Cursor ic;
+    panel(ic, p_begin);
+    int ipiece = 0;      // next piece of the issue cursor's stage
+    int head = 0;        // ring position of the next piece
+    int nfree = RP;
+    int issued = 0;      // vector-memory operations issued so far (pieces and B loads)
+    int istage = 0, cstage = 0;   // stages completely issued / consumed
+    auto pump = [&]() {
+        while (nfree > 0 && ic.p < p_end && istage - cstage < 4) {
+            const int cnt = count(ic);
+            if (ipiece == 0) set4(start0, start1, start2, start3, istage & 3, head);
+            const float* src = X + (ic.lo + 16 * ic.s + ipiece) * xs + ic.kc * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ring + head * kPieceB), 16, 0, AUX);
+            head = head + 1 == RP ? 0 : head + 1;
+            --nfree;
+            ++issued;
+            if (++ipiece == cnt) {
+                set4(mark0, mark1, mark2, mark3, istage & 3, issued);
+                ++istage;
+                ipiece = 0;
+                advance(ic);
+            }
+        }
+    };
+
+    const float* qrow = Q + (int64_t)r * dp + 4 * g;
+    f32x4 bc[16], bn[16];
+    load_b16(bn, qrow);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie16(bn);
+    pump();
+    int qmark = 0;
+
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        const int rows = (int)(hi - lo);
+        const int ns = (rows + 15) >> 4;
+        f32x4 acc[NS], tot[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { acc[s] = f32x4{0, 0, 0, 0}; tot[s] = f32x4{0, 0, 0, 0}; }
+        for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
+            issued += 16;
+            qmark = issued;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    const int ci = cstage & 3;
+                    wait_vm_dyn(issued - get4(mark0, mark1, mark2, mark3, ci));
+                    int pos = get4(start0, start1, start2, start3, ci) + r;
+                    pos = pos >= RP ? pos - RP : pos;
+                    const char* ap = ring + pos * kPieceB + g * 16;
+                    f32x4 a[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 64);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    int cnt = rows - 16 * s;
+                    cnt = cnt > 16 ? 16 : cnt;
+                    nfree += cnt;
+                    ++cstage;
+                    pump();
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bc[i][j], acc[s], 0, 0, 0);
+                    if ((kc & 1) || kc + 1 == nkc) { tot[s] = tot[s] + acc[s]; acc[s] = f32x4{0, 0, 0, 0}; }
+                }
+            }
+            wait_vm_dyn(issued - qmark);
+            tie16(bn);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < ns) {
+                const int64_t r0 = lo + 16 * s + 4 * g;
+                float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < hi) out[e] = tot[s][e];
+            }
+        }
+    }
+}
+
+template <int NS, int NW, int RP, int AUX>
+void run_pr(const char* name, const float* X, int64_t n, int dp, const float* Q, float* dots, const float* ref, int64_t ds,
+            int cus) {
+    const int n_waves = cus * NW;
+    int ppw = (int)((n + (int64_t)n_waves * 16 * NS - 1) / ((int64_t)n_waves * 16 * NS));
+    if (ppw < 1) ppw = 1;
+    int n_panels = n_waves * ppw;
+    if ((int64_t)n_panels > n) n_panels = (int)n;
+    const size_t ldsb = (size_t)NW * RP * kPieceB;
+    CK(hipFuncSetAttribute((const void*)k_scan_pr<NS, NW, RP, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    CK(hipMemset(dots, 0xFF, (size_t)16 * ds * 4));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> ts;
+    const int blocks = (n_panels + ppw * NW - 1) / (ppw * NW);
+    for (int rep = 0; rep < 22; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_scan_pr<NS, NW, RP, AUX>), dim3(blocks), dim3(NW * 64), ldsb, 0, X, (int64_t)dp, n, dp, Q, dots, ds, n_panels, ppw);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2) ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    std::vector<float> a((size_t)16 * ds), b((size_t)16 * ds);
+    CK(hipMemcpy(a.data(), dots, a.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b.data(), ref, b.size() * 4, hipMemcpyDeviceToHost));
+    long bad = 0;
+    for (int q = 0; q < 16; ++q) for (int64_t i = 0; i < n; ++i) if (memcmp(&a[q * ds + i], &b[q * ds + i], 4)) { if (bad < 3) printf("   mismatch q%d row%lld: %g vs %g\n", q, (long long)i, a[q * ds + i], b[q * ds + i]); ++bad; }
+    const double bytes = (double)n * dp * 4;
+    printf("%-28s RP=%d AUX=%d NS=%d NW=%d lds=%zu  min %.4f med %.4f ms  %.0f / %.0f GB/s  mismatches=%ld\n", name, RP, AUX, NS, NW, ldsb,
+           ts.front(), ts[ts.size() / 2], bytes / ts.front() / 1e6, bytes / ts[ts.size() / 2] / 1e6, bad);
+    fflush(stdout);
+}
+
 // scalar reference in the canonical chain order
 __global__ void k_ref(const float* X, int64_t xs, int64_t n, int dp, const float* Q, float* dots, int64_t ds) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -209,7 +379,6 @@ __global__ void k_fill_random(float* X, size_t n, unsigned long long seed) {
     }
 }
 
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 template <int NS, int NW, int MODE, int NST = 2, int AUX = 0>
 void run(const char* name, const float* X, int64_t n, int dp, const float* Q, float* dots, const float* ref, int64_t ds,
@@ -262,18 +431,12 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_ref, dim3((unsigned)((n + 255) / 256), 16), dim3(256), 0, 0, X, (int64_t)dp, n, dp, Q, ref, ds);
     CK(hipDeviceSynchronize());
     printf("n=%lld dp=%d cus=%d\n", (long long)n, dp, cus);
-    run<7, 4, 3>("4w", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<9, 3, 3>("3w", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<9, 3, 3, 3>("3w 3 stages", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<7, 4, 3, 2, 2>("4w nt", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<9, 3, 3, 2, 2>("3w nt", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<9, 3, 3, 3, 2>("3w 3 stages nt", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<13, 2, 3, 4, 2>("2w 4 stages nt", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<13, 2, 3, 4, 0>("2w 4 stages", X, n, dp, Q, dots, ref, ds, cus, true);
-    run<7, 4, 4>("4w pure DMA stream (no LDS reads)", X, n, dp, Q, dots, ref, ds, cus, false);
-    run<9, 3, 4, 3>("3w3s pure DMA stream", X, n, dp, Q, dots, ref, ds, cus, false);
-    run<9, 3, 4, 3, 2>("3w3s pure DMA stream nt", X, n, dp, Q, dots, ref, ds, cus, false);
-    run<7, 4, 2>("4w no B loads", X, n, dp, Q, dots, ref, ds, cus, false);
-    run<9, 3, 3>("3w again", X, n, dp, Q, dots, ref, ds, cus, true);
+    for (int round = 0; round < 2; ++round) {
+        run<8, 4, 3, 2, 2>("stage ring 4w x 2 nt", X, n, dp, Q, dots, ref, ds, cus, true);
+        run_pr<7, 4, 38, 2>("piece ring 4w x 38 nt", X, n, dp, Q, dots, ref, ds, cus);
+        run_pr<7, 4, 32, 2>("piece ring 4w x 32 nt", X, n, dp, Q, dots, ref, ds, cus);
+        run_pr<9, 3, 50, 2>("piece ring 3w x 50 nt", X, n, dp, Q, dots, ref, ds, cus);
+        run<9, 3, 3, 3, 2>("stage ring 3w x 3 nt", X, n, dp, Q, dots, ref, ds, cus, true);
+    }
     return 0;
 }
