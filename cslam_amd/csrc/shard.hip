@@ -338,25 +338,27 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
     for (int i = 0; i < bm; ++i) s.meta_host[1 + i] = i < b ? keyframe_ids[i] : -1;
     int64_t* my_meta = s.all_meta + (int64_t)me * (1 + bm);
     float* my_rows = s.all_rows + (int64_t)me * bm * dim;
+    // With peers, packing and both gathers run on the descriptor communicator's own stream, behind
+    // an event on the producer's stream: the compute stream (the previous step's scan) is not
+    // touched by a publish at all.
+    hipStream_t ps = st;
+    if (R > 1) {
+        ps = (hipStream_t)cslam_comm_stream(sh->comm_desc);
+        CSLAM_HIP_TRY(hipEventRecord(s.ev_src, st));
+        CSLAM_HIP_TRY(hipStreamWaitEvent(ps, s.ev_src, 0));
+    }
     CSLAM_HIP_TRY(hipMemcpyAsync(my_meta, s.meta_host, (size_t)(1 + bm) * sizeof(int64_t),
-                                 hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pack_block, dim3((unsigned)((bm + 3) / 4)), dim3(256), 0, st, new_rows_dev,
+                                 hipMemcpyHostToDevice, ps));
+    hipLaunchKernelGGL(k_pack_block, dim3((unsigned)((bm + 3) / 4)), dim3(256), 0, ps, new_rows_dev,
                        row_stride, b, bm, dim, my_rows);
     CSLAM_HIP_TRY(hipGetLastError());
     if (R > 1) {
-        // exchange on the descriptor communicator's own stream: overlaps whatever the caller's
-        // stream does next (the previous step's scan)
-        hipStream_t cs = (hipStream_t)cslam_comm_stream(sh->comm_desc);
-        CSLAM_HIP_TRY(hipEventRecord(s.ev_src, st));
-        CSLAM_HIP_TRY(hipStreamWaitEvent(cs, s.ev_src, 0));
         CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_rows, s.all_rows,
                                        (int64_t)bm * dim * sizeof(float), CSLAM_COMM_OWN_STREAM));
         CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_meta, s.all_meta,
                                        (int64_t)(1 + bm) * sizeof(int64_t), CSLAM_COMM_OWN_STREAM));
-        CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, cs));
-    } else {
-        CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, st));
     }
+    CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, ps));
     s.b = b;
     s.step = sh->pub_step++;
     s.state = 1;
