@@ -736,8 +736,12 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       int64_t dots_stride, int n_panels, int ppw,
                                                       const float* __restrict__ rnx, uint32_t row0,
                                                       uint64_t* __restrict__ cand,
-                                                      int64_t cand_stride) {
+                                                      int64_t cand_stride,
+                                                      float* __restrict__ rnq_out) {
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
+    // the query norms are computed here when the epilogue needs them (BEST) or when the caller
+    // skipped the staging kernel and wants them for the select (rnq_out)
+    const bool norms = BEST || rnq_out != nullptr;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: uniform branches
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
             bump(16);
             yq = 0;
-            if (BEST && p == p_begin) {
+            if (norms && p == p_begin) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -871,23 +875,24 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             wait_vm_dyn(yq);
             tie16(bn);
         }
-        if (BEST) {
-            if (p == p_begin) {
-                // butterfly 32, 16, 8, 4 of the norm lanes = register index xor 8, 4, 2, 1;
-                // then 2, 1 = g xor 2, 1 = lane xor 32, 16 (oracle/knn_oracle.c sumsq_wave_order)
+        if (norms && p == p_begin) {
+            // butterfly 32, 16, 8, 4 of the norm lanes = register index xor 8, 4, 2, 1;
+            // then 2, 1 = g xor 2, 1 = lane xor 32, 16 (oracle/knn_oracle.c sumsq_wave_order)
 #pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {
-                    float t2[16];
+            for (int off = 8; off >= 1; off >>= 1) {
+                float t2[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) t2[i] = ss[i] + ss[i ^ off];
+                for (int i = 0; i < 16; ++i) t2[i] = ss[i] + ss[i ^ off];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) ss[i] = t2[i];
-                }
-                float v = ss[0];
-                v = v + __shfl_xor(v, 32, kWave);
-                v = v + __shfl_xor(v, 16, kWave);
-                rnq = inv_norm_from_sumsq(__shfl(v, r, kWave));  // norm lane 0 = scan lane (r, 0)
+                for (int i = 0; i < 16; ++i) ss[i] = t2[i];
             }
+            float v = ss[0];
+            v = v + __shfl_xor(v, 32, kWave);
+            v = v + __shfl_xor(v, 16, kWave);
+            rnq = inv_norm_from_sumsq(__shfl(v, r, kWave));  // norm lane 0 = scan lane (r, 0)
+            if (rnq_out != nullptr && w == 0 && g == 0 && r < m_valid) rnq_out[r] = rnq;
+        }
+        if (BEST) {
             uint64_t best = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1587,7 +1592,7 @@ bool dma_scan_applies(const cslam_pool* p) {
 // row) composite per query and panel (best = true, *n_panels_out candidates per query)
 int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
                     int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride,
-                    int64_t* n_panels_out, hipStream_t st) {
+                    int64_t* n_panels_out, hipStream_t st, float* rnq_out = nullptr) {
     constexpr int NS = 8, NW = 4, NST = 2;
     const int64_t nw = (int64_t)p->cus * NW;
     int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
@@ -1613,7 +1618,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
         hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST>), dim3(blocks), dim3(NW * 64), lds, \
                            st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride, q_rows, \
                            m, dots, dots_stride, (int)n_panels, (int)ppw, p->inv_norm + p->v0,    \
-                           (uint32_t)p->v0, cand, cand_stride);                                   \
+                           (uint32_t)p->v0, cand, cand_stride, rnq_out);                          \
     } while (0)
     if (best) {
         if (nt) {
@@ -1640,7 +1645,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
 
 // raw dots of `m` staged queries (m <= 64) → dots[q*stride + row]
 int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t dots_stride,
-                hipStream_t st) {
+                hipStream_t st, int64_t q_stride = 0, float* rnq_out = nullptr) {
     static const int wpc_env = getenv("CSLAM_SCAN_WPC") ? atoi(getenv("CSLAM_SCAN_WPC")) : 0;
     static const int s_env = getenv("CSLAM_SCAN_S") ? atoi(getenv("CSLAM_SCAN_S")) : 0;
     // waves per CU and strips per wave of the variant that will run (profiles/r01_scan_sweep*.txt,
@@ -1665,8 +1670,9 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         const bool use_dma = dma_scan_applies(p);
         if (use_dma) {
             int64_t n_panels = 0;
-            CSLAM_TRY(launch_scan_dma(p, Qstage, p->dp, 16, m, dots, dots_stride, false, nullptr, 0,
-                                      &n_panels, st));
+            // rnq_out set: Qstage are the caller's queries read in place (no staging ran)
+            CSLAM_TRY(launch_scan_dma(p, Qstage, rnq_out ? q_stride : p->dp, rnq_out ? m : 16, m, dots,
+                                      dots_stride, false, nullptr, 0, &n_panels, st, rnq_out));
         } else if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
             p->last_scan_kernel = "k_scan_pc";
             static const int ps_env = getenv("CSLAM_SCAN_PS") ? atoi(getenv("CSLAM_SCAN_PS")) : 0;
@@ -1866,6 +1872,12 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         const int vec_ok = ((reinterpret_cast<uintptr_t>(qsrc) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         p->q_copies = mb <= 16 ? qrep_max : 1;
         p->q_copy_stride = copy_stride;
+        if (mb <= 16 && vec_ok && p->dim == p->dp && dma_scan_applies(p)) {
+            // the LDS-DMA scan reads the queries where they are and leaves 1/||q|| for the select
+            CSLAM_TRY(launch_scan(p, qsrc, mb, dots + (int64_t)q0 * dots_stride, dots_stride, st,
+                                  q_stride, p->rnq.as<float>() + q0));
+            continue;
+        }
         hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, p->q_copies), dim3(256), 0, st, qsrc,
                            q_stride, p->dim, mb, mq_pad, p->dp, p->qstage.as<float>(),
                            p->rnq.as<float>() + q0, vec_ok, copy_stride);
