@@ -28,6 +28,16 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
+# `--out DIR` (or CSLAM_GOLDEN_OUT) writes the fixtures somewhere else, e.g. to diff a fresh run
+# against the committed files; helper modules (fake_ros, ros_scenarios, test_multi_robot) and the
+# repo root are looked up next to this script, else under /root/repo
+OUT = os.environ.get("CSLAM_GOLDEN_OUT", HERE)
+if "--out" in sys.argv:
+    OUT = sys.argv[sys.argv.index("--out") + 1]
+    os.makedirs(OUT, exist_ok=True)
+TESTS = os.path.dirname(HERE) if os.path.exists(os.path.join(os.path.dirname(HERE), "fake_ros.py")) \
+    else "/root/repo/tests"
+ROOT = os.path.dirname(TESTS)
 
 
 def _install_shims():
@@ -120,7 +130,7 @@ def gen_knn():
     add_case("ties_zero16", X, np.vstack([X[3], rs.rand(16)]).astype(np.float32), 5)
 
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "knn_ref.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "knn_ref.npz"), **out)
     print("knn_ref.npz:", cases)
 
 
@@ -229,7 +239,7 @@ def gen_mac():
         print(name, "iters", len(trace), "lambda0", trace[0][1], "last", trace[-1][1], "eigsh",
               float(np.sort(ev)[1]), "selected", len(selected))
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "mac_ref.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "mac_ref.npz"), **out)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -331,7 +341,7 @@ def gen_acm():
                                        selected=_edge_list(sel),
                                        selected_big_budget=_edge_list(sel_b))
 
-    with open(os.path.join(HERE, "acm_ref.json"), "w") as f:
+    with open(os.path.join(OUT, "acm_ref.json"), "w") as f:
         json.dump(traces, f)
     print("acm_ref.json:", list(traces))
 
@@ -372,8 +382,8 @@ def gen_lcsm():
             events.append(["other", r, kf, None if m is None else _edge_list([m])[0]])
     cand = {str(k): float(v.weight) for k, v in l.candidate_selector.candidate_edges.items()}
     sel = l.select_candidates(10, {0: True, 1: True, 2: True})
-    np.savez_compressed(os.path.join(HERE, "lcsm_desc.npz"), desc=desc)
-    with open(os.path.join(HERE, "lcsm_ref.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "lcsm_desc.npz"), desc=desc)
+    with open(os.path.join(OUT, "lcsm_ref.json"), "w") as f:
         json.dump(dict(params=params(0, nb_robots, thr=0.6), events=events, candidates=cand,
                        selected=_edge_list(sel)), f)
     print("lcsm_ref.json: events", len(events), "candidates", len(cand), "selected", len(sel))
@@ -410,7 +420,7 @@ def gen_cfg1():
     l.candidate_selector.add_fixed_edge(EdgeInterRobot(0, 999, 1, 999, 1.0))
     with contextlib.redirect_stdout(io.StringIO()):
         sel = l.select_candidates(100, {0: True, 1: True})
-    with open(os.path.join(HERE, "cfg1_ref.json"), "w") as f:
+    with open(os.path.join(OUT, "cfg1_ref.json"), "w") as f:
         json.dump(dict(params=params(), matches=matches, candidates=cand,
                        selected=_edge_list(sel)), f)
     print("cfg1_ref.json: candidates", len(cand), "selected", len(sel))
@@ -445,7 +455,7 @@ def gen_broker():
     cases["single_robot"] = dict(selection=_edge_list(cand[:5]), in_range=[0],
                                  covers=Broker(cand[:5], [0]).brokerage(True), dialog=[],
                                  is_bipartite=False)
-    with open(os.path.join(HERE, "broker_ref.json"), "w") as f:
+    with open(os.path.join(OUT, "broker_ref.json"), "w") as f:
         json.dump(cases, f)
     print("broker_ref.json:", {k: [len(c) for c in v["covers"]] for k, v in cases.items()})
 
@@ -508,7 +518,7 @@ def gen_vpr():
                 out[f"vlad_{tag}_conv_b"] = layer.conv.bias.numpy().copy()
             out[f"vlad_{tag}_centroids"] = layer.centroids.numpy().copy()
             out[f"vlad_{tag}_out"] = layer(x).numpy()
-    np.savez_compressed(os.path.join(HERE, "vpr_ref.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "vpr_ref.npz"), **out)
     print("vpr_ref.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
@@ -591,7 +601,7 @@ def _install_ros_stand_ins():
 
 
 def gen_gdlcd():
-    sys.path.insert(0, os.path.dirname(HERE))     # tests/: fake_ros, ros_scenarios
+    sys.path.insert(0, TESTS)                     # tests/: fake_ros, ros_scenarios
     msgs = _install_ros_stand_ins()
     from fake_ros import FakeBus, FakeNode as BusNode
     import ros_scenarios
@@ -613,9 +623,10 @@ def gen_gdlcd():
             m.device = torch.device("cpu")
         return node, g
 
-    desc = np.load(os.path.join(HERE, "lcsm_desc.npz"))["desc"]
+    src = OUT if os.path.exists(os.path.join(OUT, "lcsm_desc.npz")) else HERE
+    desc = np.load(os.path.join(src, "lcsm_desc.npz"))["desc"]
     traces = ros_scenarios.run_all(make_robot, msgs, FakeBus, desc)
-    with open(os.path.join(HERE, "gdlcd_ref.json"), "w") as f:
+    with open(os.path.join(OUT, "gdlcd_ref.json"), "w") as f:
         json.dump(traces, f)
     print("gdlcd_ref.json:", {k: sorted(v) for k, v in traces.items()})
 
@@ -625,8 +636,8 @@ def gen_gdlcd():
 # tests/test_multi_robot.py in the arrival order the sharded protocol documents
 # ----------------------------------------------------------------------------------------------
 def gen_cfg4():
-    sys.path.insert(0, os.path.dirname(HERE))
-    sys.path.append(os.path.dirname(os.path.dirname(HERE)))   # repo root: oracle/ (block generator's import)
+    sys.path.insert(0, TESTS)
+    sys.path.append(ROOT)   # repo root: oracle/ (the block generator's module imports it)
     import test_multi_robot as tm
 
     def make(robot_id, nb, k, gap):
@@ -675,7 +686,7 @@ def gen_cfg4():
             threshold=tm.THR, union=union, per_robot=per_robot,
             intra={str(r): v for r, v in intra.items()},
             pool_sizes=[int(robots[r].local_nnsm.n) for r in range(world)])
-    with open(os.path.join(HERE, "cfg4_ref.json"), "w") as f:
+    with open(os.path.join(OUT, "cfg4_ref.json"), "w") as f:
         json.dump(out, f)
     print("cfg4_ref.json:", {k: (len(v["union"]), sum(len(x) for x in v["intra"].values()))
                              for k, v in out.items()})
