@@ -1608,12 +1608,12 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
 #define CSLAM_DMA_LAUNCH(AUX, BEST)                                                               \
     do {                                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
+        static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
+        if (!attr_set[p->device & 63]) {                                                          \
             CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST>,    \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
-            attr_set = true;                                                                      \
+            attr_set[p->device & 63] = true;                                                      \
         }                                                                                         \
         hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST>), dim3(blocks), dim3(NW * 64), lds, \
                            st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride, q_rows, \
@@ -1692,12 +1692,12 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
             CSLAM_HIP_TRY(hipMemsetAsync(p->fault.p, 0, sizeof(int), st));
 #define CSLAM_PC_LAUNCH(SS, WW)                                                                   \
     do {                                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
+        static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
+        if (!attr_set[p->device & 63]) {                                                          \
             CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_pc<SS, WW>,                     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
-            attr_set = true;                                                                      \
+            attr_set[p->device & 63] = true;                                                      \
         }                                                                                         \
         hipLaunchKernelGGL((k_scan_pc<SS, WW>), dim3((unsigned)blocks), dim3(WW * 64), lds, st,   \
                            p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,         \
@@ -1816,12 +1816,12 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
                 float* dr = dots + row0;
 #define CSLAM_GD_LAUNCH(TMV, SL)                                                                   \
     do {                                                                                           \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        static bool attr_set[64] = {};                                                             \
+        if (!attr_set[p->device & 63]) {                                                           \
             CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<TMV, SL>,                    \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                               (int)lds));                                          \
-            attr_set = true;                                                                       \
+            attr_set[p->device & 63] = true;                                                       \
         }                                                                                          \
         hipLaunchKernelGGL((k_gemm_dma<TMV, SL>), dim3((unsigned)nblocks), dim3(256), lds, st, xr, \
                            p->xs, nrows, p->dp, p->qstage.as<float>(), m, dr, dots_stride,         \
