@@ -294,16 +294,20 @@ def _sequential_reference_with(blocks, world, steps, thr=THR):
 
 @pytest.mark.gpu
 def test_cfg4_full_size_protocol_properties(gpu):
-    """BASELINE.json configs[3] at its real size on ONE GPU: 8 robot shards (threads) x 25 000
-    keyframes x 4096-d resident, then protocol steps whose new descriptors are planted copies of
-    rows that live in OTHER shards.  Size-independent properties: every planted copy produces the
-    candidate (owner, row) with similarity 1, every replica of the candidate set is identical,
-    no candidate is produced for fresh random descriptors under a 0.95 threshold."""
+    """BASELINE.json configs[3] at its real size on ONE GPU, on the PRODUCT path (DeviceShard:
+    csrc/shard.hip + csrc/comm.hip through the C ABI): 8 robot shards (threads, `LocalGroup`
+    transport) x 25 000 keyframes x 4096-d resident, then protocol steps whose new descriptors
+    are planted copies of rows that live in OTHER shards.  Size-independent properties: every
+    planted copy produces the candidate (owner, row) with similarity 1, every replica of the
+    candidate set is identical, no candidate is produced for fresh random descriptors under a
+    0.95 threshold.  (40 gathered descriptors per step: the 33..64-query scan variant.)"""
     import threading
-    from cslam_amd.multi_robot import HipPoolMatcher, ShardedLoopClosureMatching
+    from cslam_amd.multi_robot import CallbackComm, DeviceShard, LocalGroup
+    from cslam_amd.nns_matching import NearestNeighborsMatching
     world, rows, dim, steps, per_step = 8, 25_000, 4096, 3, 4
-    shared = ThreadComm.Shared(world)
-    results, errors, planted_all = [None] * world, [], {}
+    grp_d, grp_r = LocalGroup(world), LocalGroup(world)
+    ready = threading.Barrier(world)
+    results, errors, kernels = [None] * world, [], [None] * world
     dev = torch.device("cuda", 0)
     # what every rank plants at every step: (owner shard, owner row) — owner != rank
     rs = np.random.RandomState(0)
@@ -318,12 +322,14 @@ def test_cfg4_full_size_protocol_properties(gpu):
     def run(rank):
         try:
             torch.cuda.set_device(0)
-            m = HipPoolMatcher(dim, capacity_hint=rows + steps * (per_step + 1))
+            pool = NearestNeighborsMatching(dim=dim, capacity_hint=rows + steps * (per_step + 1))
             x = base_rows(rank)
-            m.add_rows(x, list(range(rows)))
+            pool.add_items_tensor(x, list(range(rows)))
             pools[rank] = x
-            sh = ShardedLoopClosureMatching(ThreadComm(shared, rank), m, 0.95, max_block=per_step + 1)
-            shared.barrier.wait()           # every shard's base rows exist before anybody plants
+            cd = CallbackComm(rank, world, 0, grp_d.transport(rank))
+            cr = CallbackComm(rank, world, 0, grp_r.transport(rank))
+            sh = DeviceShard(pool, rank, world, per_step + 1, 0.95, cd, cr)
+            ready.wait()                    # every shard's base rows exist before anybody plants
             for t in range(steps):
                 copies = torch.stack([pools[s][j] for s, j in plan[(t, rank)]])
                 g = torch.Generator(device=dev).manual_seed(9000 + 10 * t + rank)
@@ -331,16 +337,21 @@ def test_cfg4_full_size_protocol_properties(gpu):
                 block = torch.cat([copies, fresh]).contiguous()
                 kfs = [rows + t * (per_step + 1) + i for i in range(per_step + 1)]
                 sh.step(block, kfs)
+            kernels[rank] = gpu.cslam_pool_scan_kernel(pool.handle).decode()
             results[rank] = {k: float(v.weight) for k, v in sh.candidate_selector.candidate_edges.items()}
+            assert pool.n == rows + steps * (per_step + 1)
+            sh.close(); cd.close(); cr.close(); pool.close()
         except Exception as e:  # surface worker failures in the main thread
             errors.append(e)
-            shared.barrier.abort()
+            for bar in (grp_d.barrier, grp_r.barrier, ready):
+                bar.abort()
 
     threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     [t.start() for t in threads]
     [t.join(timeout=600) for t in threads]
     assert not errors, errors
     assert all(r is not None for r in results)
+    assert all(k.startswith("k_scan") for k in kernels), kernels
     for r in range(1, world):
         assert results[r] == results[0]                         # identical replicas
     expected = set()
