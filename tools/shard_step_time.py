@@ -47,12 +47,17 @@ def publish():
     pub[0] += 1
 
 
+host = [0.0]
+
+
 def run(n):
     matched = fetched = recs = 0
     publish()
     for t in range(n):
+        h0 = time.perf_counter()
         publish()
         sh.match(st)
+        host[0] += time.perf_counter() - h0      # host time of enqueueing one step (no waiting)
         matched += 1
         if matched - fetched > 1:
             recs += len(sh.fetch_records())
@@ -67,11 +72,12 @@ def run(n):
 
 
 run(10)
+host[0] = 0.0
 t0 = time.perf_counter()
 recs = run(steps)
 dt = (time.perf_counter() - t0) / (steps + 1)
-print(f"R={R} per_rank={per_rank}: {dt * 1e3:.4f} ms per step, {recs / (steps + 1):.1f} records per step, "
-      f"kernel {L.cslam_pool_scan_kernel(pool.handle).decode()}")
+print(f"R={R} per_rank={per_rank}: {dt * 1e3:.4f} ms per step ({host[0] / steps * 1e3:.4f} ms of host enqueue time), "
+      f"{recs / (steps + 1):.1f} records per step, kernel {L.cslam_pool_scan_kernel(pool.handle).decode()}")
 
 q = torch.rand((16, D), device=dev, generator=g)
 oi = torch.empty((16, 1), dtype=torch.int32, device=dev)
