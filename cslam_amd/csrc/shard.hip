@@ -178,6 +178,7 @@ struct cslam_shard {
     int me = 0, R = 1, b_max = 0, dim = 0, device = 0;
     int k_local = 0, min_inbetween = 0, K = 1;
     bool fused = true;
+    bool best2 = false;  // no intra-robot matching, <= 16 gathered descriptors: split best-match scan
     double thr = 0.0;
     int32_t* kf_of_row = nullptr;
     int64_t kf_cap = 0;
@@ -247,6 +248,10 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
     sh->k_local = sh->fused ? nb_best_matches : 0;   // bulk blocks: inter-robot matching only
     sh->min_inbetween = intra_min_inbetween;
     sh->K = max_block + (sh->k_local > 1 ? sh->k_local : 1);
+    // inter-robot matching only (frontend.enable_intra_robot_loop_closures = false, the node's
+    // default, loop_closure_detection_node.py:36) asks two questions per gathered descriptor — best
+    // old row, best row of the new block: one split best-match scan, no top-K lists
+    sh->best2 = nb_best_matches == 0 && (int64_t)nb_robots * max_block <= 16;
     sh->rec_slots = 3 * (int64_t)nb_robots * max_block;
     int rc = CSLAM_OK;
     hipError_t e = hipSetDevice(sh->device);
@@ -259,7 +264,7 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
         A(dalloc(&s.all_rows, M * sh->dim));
         A(dalloc(&s.all_meta, (size_t)nb_robots * (1 + max_block)));
         A(dalloc(&s.recs_all, (size_t)nb_robots * sh->rec_slots));
-        if (sh->fused) {
+        if (sh->fused && !sh->best2) {
             A(dalloc(&s.topk_idx, M * sh->K));
             A(dalloc(&s.topk_sim, M * sh->K));
         } else {
@@ -379,7 +384,18 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     const float* my_rows = s.all_rows + (int64_t)me * bm * dim;
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
     const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);
-    if (sh->fused) {
+    if (sh->best2) {
+        // append first, then ONE launch: best row before n0 and best row of the new block
+        if (s.b > 0) {
+            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
+            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
+        }
+        CSLAM_TRY(cslam_pool_search_best_split_dev(sh->pool, s.all_rows, dim, M, n0, s.idx_a, s.sim_a,
+                                                   s.idx_c, s.sim_c, st));
+        hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
+                           n0, sh->kf_of_row, s.b, sh->thr, nullptr, nullptr, 1, 0, 0, s.idx_a, s.sim_a,
+                           s.idx_c, s.sim_c, my_recs);
+    } else if (sh->fused) {
         // append first, then ONE scan: the sorted top-K (K > b) of every gathered descriptor
         // holds both its best older row and its best row of the new block
         if (s.b > 0) {

@@ -395,3 +395,57 @@ def test_full_size_properties(gpu):
     o = oracle_knn.similarities(rows, Q[:1].cpu().numpy())
     assert o[0].tobytes() == s1[0].tobytes()
     m.close()
+
+
+@pytest.mark.parametrize("n,d,m,split", [
+    (18000, 512, 16, 17990),      # the sharded step's shape: a handful of new rows behind the split
+    (18000, 512, 5, 17999),       # one new row
+    (40000, 256, 16, 123),        # split inside the first panel
+    (3000, 256, 9, 1500),         # small pool: fewer panels than waves
+    (70, 256, 16, 64),            # one strip per panel, partial last strip
+    (2500, 1024, 40, 2400),       # > 16 queries: one launch per 16
+    (1200, 48, 7, 1000),          # dim % 256 != 0: two range searches behind the same entry point
+])
+def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
+    """cslam_pool_search_best_split_dev: best row before `split` and best row from `split` on in
+    one scan launch with the finish inside it (last-arriver reduction) — bit-identical to the
+    oracle on the two row ranges, ties to the lowest row on either side, repeated launches reuse
+    the ticket."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    from cslam_amd import _lib
+    rs = np.random.RandomState(n + d + m)
+    X = rs.rand(n, d).astype(np.float32)
+    Q = rs.rand(m, d).astype(np.float32)
+    if split + 2 < n:
+        X[n - 1] = X[split]                         # tie behind the split → row `split`
+        Q[0] = X[split]
+    if split > 40:
+        X[split - 1] = X[3]                         # tie in front of it → row 3
+        Q[m - 1] = X[3]
+    pool = _pool(gpu, X, dim=d, capacity_hint=n)
+    qd = torch.from_numpy(Q).cuda()
+    out = [torch.full((m,), -7, dtype=torch.int32, device="cuda"), torch.zeros(m, device="cuda"),
+           torch.full((m,), -7, dtype=torch.int32, device="cuda"), torch.zeros(m, device="cuda")]
+    oa_idx, oa_sim, _ = oracle_knn.search(X[:split], Q, 1)
+    oc_idx, oc_sim, _ = oracle_knn.search(X[split:], Q, 1)
+    for rep in range(3):
+        _lib.check(gpu.cslam_pool_search_best_split_dev(
+            pool.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split,
+            *[ctypes.c_void_p(t.data_ptr()) for t in out], None))
+        torch.cuda.synchronize()
+        ia, sa, ic, sc = [t.cpu().numpy() for t in out]
+        np.testing.assert_array_equal(ia, oa_idx[:, 0])
+        np.testing.assert_array_equal(ic, oc_idx[:, 0] + split)
+        assert sa.tobytes() == oa_sim[:, 0].tobytes()
+        assert sc.tobytes() == oc_sim[:, 0].tobytes()
+    if split + 2 < n:
+        assert ic[0] == split
+    if split > 40:
+        assert ia[m - 1] == 3
+    # the plain search_best on the same handle still agrees (one window, same ticket)
+    rows, sims = pool.search_batch(Q[:min(m, 16)], 1)
+    o_idx, o_sim, _ = oracle_knn.search(X, Q[:min(m, 16)], 1)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    pool.close()

@@ -228,3 +228,32 @@ def test_device_shard_single_robot_and_pipelining(gpu):
     assert (9, 2) in [(a, b) for a, b, _ in local]
     assert sh.candidate_selector.candidate_edges == {}
     sh.close(); pool.close()
+
+
+@pytest.mark.parametrize("world,maxb", [(2, 5), (3, 5), (4, 4)])
+def test_device_shard_split_best_mode(gpu, world, maxb):
+    """Inter-robot matching only (nb_best_matches = 0: frontend.enable_intra_robot_loop_closures
+    off, the node default) with <= 16 gathered descriptors per step: ONE scan launch per step
+    answers "best old row" and "best row of the block just appended" (split best-match, finish
+    inside the launch).  256-d so the LDS-DMA scan runs; same candidate set as the sequential
+    reference semantics, identical replicas and record streams."""
+    steps, dim = 12, 256
+    rs = np.random.RandomState(31 + world)
+    places = rs.rand(25, dim).astype(np.float32)
+    blocks, nxt = {}, [0] * world
+    for t in range(steps):
+        for r in range(world):
+            b = int(rs.randint(0, maxb + 1))
+            x = places[rs.randint(0, len(places), size=b)] + 0.05 * rs.rand(b, dim).astype(np.float32)
+            blocks[(t, r)] = (x.astype(np.float32), list(range(nxt[r], nxt[r] + b)))
+            nxt[r] += b
+    results, local, records = _run_shards(world, steps, blocks, maxb, 0, 0, dim=dim, thr=0.9)
+    union, _ = _sequential_reference_with(blocks, world, steps, thr=0.9)
+    assert len(union) > 10
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for key in union:
+            assert abs(results[r][key] - union[key]) <= 1e-7
+        assert results[r] == results[0]
+        assert records[r].tobytes() == records[0].tobytes()
+        assert local[r] == []
