@@ -13,8 +13,9 @@ Workload (configs[1], fits one GPU): every rank is one robot holding a resident 
   N > 1   one step = the sharded protocol of SURVEY.md §8e through the C ABI
           (cslam_amd.multi_robot.DeviceShard → csrc/shard.hip, csrc/comm.hip): every rank
           publishes 16/N new descriptors, RCCL all-gather of the blocks, the own block is
-          appended to the pool, ONE scan of the pool for all 16 gathered descriptors (foreign ones:
-          inter-robot match, lcsm.py:58-76 / 37-56; own ones: intra-robot match, lcsm.py:78-97),
+          appended to the pool, ONE scan launch of the pool for all 16 gathered descriptors (best
+          old row and best row of the new block: inter-robot match, lcsm.py:58-76 / 37-56;
+          intra-robot matching off as in the node's defaults, CSLAM_BENCH_INTRA=1 turns it on),
           20-byte match records built on the device, RCCL all-gather of the records, records
           fetched by the host.  16 best-match evaluations per rank per step, per-GPU work fixed
           as N grows (weak scaling): value = N * 16 / step time.  The exchange of step t+1 is
@@ -199,9 +200,13 @@ def main():
             comm_d = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
             comm_r = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
         # threshold 0: every evaluation on non-negative data yields a candidate;
-        # nb_best_matches / min_inbetween: defaults of loop_closure_detection_node.py:28-29
-        shard = DeviceShard(pool, rank, world, per_rank, 0.0, comm_d, comm_r, nb_best_matches=10,
-                            intra_min_inbetween=10)
+        # inter-robot matching only, as SURVEY §8e defines the step and as the node runs by default
+        # (frontend.enable_intra_robot_loop_closures = False, loop_closure_detection_node.py:36):
+        # per GPU the same 16 best-match evaluations per step as at N = 1.
+        # CSLAM_BENCH_INTRA=1 adds match_local_loop_closures (nb_best_matches = 10, lcsm.py:78-97).
+        intra = os.environ.get("CSLAM_BENCH_INTRA") == "1"
+        shard = DeviceShard(pool, rank, world, per_rank, 0.0, comm_d, comm_r,
+                            nb_best_matches=10 if intra else 0, intra_min_inbetween=10)
         blocks = torch.rand((8, per_rank, D), device=dev, generator=g)   # new keyframes, cycled
         next_kf = [N]
 
@@ -282,7 +287,7 @@ def main():
     #   pool rows N*D*4 + queries M*D*4 + results M*k*8
     scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()
     n_rows_scanned = N if world == 1 else N + (settle + args.warmup + args.steps // 2) * per_rank
-    k_sel = 1 if world == 1 else per_rank + 10
+    k_sel = 1 if world == 1 else (per_rank + 10 if os.environ.get("CSLAM_BENCH_INTRA") == "1" else 2)
     alg_bytes = n_rows_scanned * D * 4 + gathered_rows * D * 4 + gathered_rows * k_sel * 8
     achieved = alg_bytes / (scan_ms.value * 1e-3) / 1e9 if scan_ms.value > 0 else 0.0
     # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes and
@@ -303,7 +308,7 @@ def main():
     if world > 1:
         workload = (f"cfg2 pool per GPU under the cfg4 protocol: every rank publishes {per_rank} new "
                     "descriptors per step, RCCL all-gather, append, one scan of the pool for all "
-                    f"{gathered_rows} gathered descriptors (inter- and intra-robot match), match "
+                    f"{gathered_rows} gathered descriptors (inter-robot match: best old row + best new row), match "
                     "records built on the device, RCCL all-gather of the records, fetched by the host")
     result = {
         "metric": METRIC,

@@ -61,8 +61,8 @@ SIGNATURES = {
     "cslam_pool_search_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp, _vp]),
     "cslam_pool_search_range_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64,
                                                _c.c_int64, _vp, _vp, _vp]),
-    "cslam_pool_search_best_split_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int64, _vp, _vp,
-                                                    _vp, _vp, _vp]),
+    "cslam_pool_search_best_split_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int64, _c.c_int64,
+                                                    _vp, _vp, _vp, _vp, _vp]),
     "cslam_pool_similarities_dev": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int64, _vp]),
     "cslam_pool_profile_begin": (_c.c_int, [_vp, _c.c_int]),
     "cslam_pool_profile_begin_sampled": (_c.c_int, [_vp, _c.c_int, _c.c_int]),

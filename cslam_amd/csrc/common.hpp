@@ -57,4 +57,20 @@ struct DevBuf {
 
 int device_cu_count(int device_id, int* cus);
 
+// knn.hip → shard.hip (internal).  pool_append_on: cslam_pool_add_dev without the cross-stream
+// ordering of the public entry points (the shard orders its streams with its own events);
+// pool_order_on: make the pool's other entry points wait for what `st` has been given so far.
+int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64_t row_stride,
+                   hipStream_t st);
+int pool_order_on(cslam_pool_t* p, hipStream_t st);
+// candidates of a split best-match scan, see knn.hip
+struct BestCandidates {
+    const uint64_t* a = nullptr;  // [16][stride] composites of rows < split, n valid per query
+    const uint64_t* c = nullptr;  // ... of rows >= split
+    int64_t stride = 0, n = 0;
+};
+int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
+                               int64_t split_row, int64_t row_hi, hipStream_t st,
+                               BestCandidates* out, bool* applied);
+
 }  // namespace cslam

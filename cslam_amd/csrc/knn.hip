@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "composite.hpp"
 
 using namespace cslam;
 
@@ -48,22 +49,6 @@ inline int64_t query_chunk(int64_t sims_stride) {
 __host__ __device__ inline int64_t pad16(int64_t d) { return (d + 15) / 16 * 16; }
 
 // ---------------------------------------------------------------------------------------------
-// composites: (orderable(sim) << 32) | (0xFFFFFFFF - row)  → max = best similarity, lowest row
-// ---------------------------------------------------------------------------------------------
-__device__ inline uint32_t f2ord(float s) {
-    if (s == 0.0f) s = 0.0f;  // -0 → +0
-    uint32_t u = __float_as_uint(s);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ inline float ord2f(uint32_t o) {
-    uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
-    return __uint_as_float(u);
-}
-__device__ inline uint64_t make_comp(float s, uint32_t row) {
-    return ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - row);
-}
-
-// ---------------------------------------------------------------------------------------------
 // 1 / max(||row||, 1e-8); the sum of squares arrives in wave64 order (oracle/knn_oracle.c:
 // sumsq_wave_order): lane l takes floats 256t + 4l + c, xor butterfly 32 .. 1
 // ---------------------------------------------------------------------------------------------
@@ -73,28 +58,6 @@ __device__ inline float inv_norm_from_sumsq(float ss) {
     float nrm = __builtin_sqrtf(ss);
     if (!(nrm > 1e-8f)) nrm = 1e-8f;
     return 1.0f / nrm;
-}
-
-// 64-lane maximum of a 64-bit composite on the VALU (DPP) — `__shfl_xor` of a 64-bit value is two
-// LDS-crossbar ds_bpermute per step, 12 dependent ones per round of the select.  0 is the
-// identity (an empty composite).  Result in every lane.
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ inline uint64_t dpp_mov_u64(uint64_t v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
-    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
-}
-__device__ inline uint64_t wave_max_u64(uint64_t m) {
-    uint64_t o;
-    o = dpp_mov_u64<0xB1>(m);        m = o > m ? o : m;   // quad_perm [1,0,3,2]
-    o = dpp_mov_u64<0x4E>(m);        m = o > m ? o : m;   // quad_perm [2,3,0,1]
-    o = dpp_mov_u64<0x141>(m);       m = o > m ? o : m;   // row_half_mirror
-    o = dpp_mov_u64<0x140>(m);       m = o > m ? o : m;   // row_mirror: every lane = max of its row
-    o = dpp_mov_u64<0x142, 0xA>(m);  m = o > m ? o : m;   // row_bcast15: rows 1, 3 take rows 0, 2
-    o = dpp_mov_u64<0x143, 0xC>(m);  m = o > m ? o : m;   // row_bcast31: rows 2, 3 take rows 0..1
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, 63);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), 63);
-    return ((uint64_t)hi << 32) | lo;
 }
 
 __device__ inline float ld_or_zero(const float* s, int k, int dim) { return k < dim ? s[k] : 0.0f; }
@@ -752,24 +715,16 @@ struct DmaCursor {   // position of a stage in a wave's work list
 //   epilogue applies (dot * rn(x)) * rn(q) and keeps the panel's best (similarity desc, row asc)
 //   composite per query; the queries may be read in place (q_rows = m, any stride) — no
 //   staging kernel, no dots round trip.  Every wave keeps a running best over its panels and
-//   leaves ONE composite per query (two when the row window is split, below).
-//   Finish inside the launch (BestFinish, fin.ticket != nullptr): a wave that is done publishes
-//   its composites (agent-scope stores), fences and takes a ticket; the wave that draws the last
-//   ticket reduces the n_waves composites of every query and writes (row, similarity) — the
-//   search is ONE launch.  `split` cuts the window into rows < split (outputs idx_a / sim_a) and
-//   rows >= split (idx_c / sim_c): the sharded step asks for the best OLD row and the best row of
-//   the block it has just appended in the same pass (csrc/shard.hip).
-struct BestFinish {
-    unsigned* ticket = nullptr;  // zero between launches (the finisher resets it)
-    int n_waves = 0;             // waves that take a ticket (those with at least one panel)
-    int64_t split = 0;           // window-relative row; >= n: one window
-    uint64_t* cand_c = nullptr;  // [16][cand_stride] composites of the rows >= split
-    int32_t* idx_a = nullptr;
-    float* sim_a = nullptr;
-    int32_t* idx_c = nullptr;
-    float* sim_c = nullptr;
-};
-
+//   leaves ONE composite per query, a small select launch reduces the <= 1024 of them.
+//   Split window (cand_c != nullptr): rows < split and rows >= split (window-relative) are kept
+//   apart — two composites per query and wave: the sharded step asks for the best OLD row and
+//   the best row of the block it has just appended in the same pass (csrc/shard.hip).
+//   Measured and rejected (round 2, commit 775bacb holds the code): finishing inside the launch — waves
+//   fold through LDS, block tickets, the last block's wave reduces and writes the results.  The
+//   dependent chain at the tail (write-through stores complete → ticket atomic → invalidate →
+//   loads, ~1.5 us of memory-side latency each) cost 7.4 us against 4.5 us for the select launch
+//   behind the scan (265.9 vs 263.0 us per step); with a release fence per block (buffer_wbl2)
+//   +8 us more.
 template <int NS, int NW, int NST, int AUX, bool BEST>
 __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
                                                       int64_t n, int dp,
@@ -781,7 +736,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       uint64_t* __restrict__ cand,
                                                       int64_t cand_stride,
                                                       float* __restrict__ rnq_out,
-                                                      BestFinish fin) {
+                                                      int64_t split, uint64_t* __restrict__ cand_c) {
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     // the query norms are computed here when the epilogue needs them (BEST) or when the caller
     // skipped the staging kernel and wants them for the select (rnq_out)
@@ -795,13 +750,6 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     const int p_begin = w * ppw;
     int p_end = p_begin + ppw;
     if (p_end > n_panels) p_end = n_panels;
-    // finish inside the launch: block ticket and the waves' composites live behind the rings
-    unsigned* lticket = reinterpret_cast<unsigned*>(dma_lds + NW * NST * kDmaStageB);
-    uint64_t* lcomp = reinterpret_cast<uint64_t*>(dma_lds + NW * NST * kDmaStageB + 16);
-    if (BEST && fin.ticket != nullptr) {
-        if (threadIdx.x == 0) *lticket = 0;
-        __syncthreads();  // the only barrier: before any wave leaves
-    }
     if (p_begin >= p_end) return;
 
     auto panel = [&](DmaCursor& c, int p) {
@@ -946,7 +894,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         }
         if (BEST) {
             uint64_t best = 0, best_c = 0;
-            const bool two = fin.split < hi;  // wave-uniform: rows >= split in this panel
+            const bool two = split < hi;  // wave-uniform: rows >= split in this panel
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (s < ns) {
@@ -956,7 +904,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                         if (r0 + e < hi) {
                             const float sim = (tot[s][e] * rnx[r0 + e]) * rnq;
                             const uint64_t c = make_comp(sim, row0 + (uint32_t)(r0 + e));
-                            if (two && r0 + e >= fin.split)
+                            if (two && r0 + e >= split)
                                 best_c = c > best_c ? c : best_c;
                             else
                                 best = c > best ? c : best;
@@ -989,92 +937,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             }
         }
     }
-    if (BEST) {
-        const bool split_on = fin.cand_c != nullptr;
-        if (fin.ticket == nullptr) {
-            // no finish in the launch: one composite per query and WAVE for a select launch
-            if (g == 0 && r < m_valid) {
-                cand[(int64_t)r * cand_stride + w] = wbest_a;
-                if (split_on) fin.cand_c[(int64_t)r * cand_stride + w] = wbest_c;
-            }
-            return;
-        }
-        // level 1, inside the block through LDS: the block's last wave folds its waves' composites
-        if (g == 0) {
-            lcomp[wave * 16 + r] = wbest_a;
-            lcomp[(NW + wave) * 16 + r] = wbest_c;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        unsigned t = 0;
-        if (lane == 0)
-            t = __hip_atomic_fetch_add(lticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-        int active = fin.n_waves - blockIdx.x * NW;  // waves of this block that hold panels
-        active = active > NW ? NW : active;
-        if (t != (unsigned)(active - 1)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane < 16) {
-            uint64_t ba = 0, bc = 0;
-            for (int wv = 0; wv < active; ++wv) {
-                const uint64_t c = lcomp[wv * 16 + lane], c2 = lcomp[(NW + wv) * 16 + lane];
-                ba = c > ba ? c : ba;
-                bc = c2 > bc ? c2 : bc;
-            }
-            // agent scope: the finisher may sit on another XCD
-            __hip_atomic_store(cand + (int64_t)lane * cand_stride + blockIdx.x, ba, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (split_on)
-                __hip_atomic_store(fin.cand_c + (int64_t)lane * cand_stride + blockIdx.x, bc,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // level 2: the wave that draws the last block ticket reduces one composite per block
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0)
-            t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-        if (t != gridDim.x - 1) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        uint64_t va[16], vc[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            va[q] = 0;
-            vc[q] = 0;
-        }
-        for (int i = lane; i < (int)gridDim.x; i += kWave) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (q < m_valid) {
-                    const uint64_t c = __hip_atomic_load(cand + (int64_t)q * cand_stride + i,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    va[q] = c > va[q] ? c : va[q];
-                    if (split_on) {
-                        const uint64_t c2 =
-                            __hip_atomic_load(fin.cand_c + (int64_t)q * cand_stride + i,
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vc[q] = c2 > vc[q] ? c2 : vc[q];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            if (q < m_valid) {
-                const uint64_t ba = wave_max_u64(va[q]);
-                if (lane == 0) {
-                    fin.idx_a[q] = ba ? (int32_t)(0xFFFFFFFFu - (uint32_t)(ba & 0xFFFFFFFFu)) : -1;
-                    fin.sim_a[q] = ba ? ord2f((uint32_t)(ba >> 32)) : -INFINITY;
-                }
-                if (split_on) {
-                    const uint64_t bc = wave_max_u64(vc[q]);
-                    if (lane == 0) {
-                        fin.idx_c[q] = bc ? (int32_t)(0xFFFFFFFFu - (uint32_t)(bc & 0xFFFFFFFFu)) : -1;
-                        fin.sim_c[q] = bc ? ord2f((uint32_t)(bc >> 32)) : -INFINITY;
-                    }
-                }
-            }
-        }
-        if (lane == 0)
-            __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (BEST && g == 0 && r < m_valid) {
+        cand[(int64_t)r * cand_stride + w] = wbest_a;
+        if (cand_c != nullptr) cand_c[(int64_t)r * cand_stride + w] = wbest_c;
     }
 }
 
@@ -1597,6 +1462,25 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
     out_sim[j] = -INFINITY;
 }
 
+// final level of search_best: one block per (query, window) reduces the waves' composites.
+// window 1 (blockIdx.y == 1) exists for the split search only.
+__global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ cand_a,
+                                                   const uint64_t* __restrict__ cand_c,
+                                                   int64_t stride, int64_t n_cand,
+                                                   int32_t* __restrict__ idx_a,
+                                                   float* __restrict__ sim_a,
+                                                   int32_t* __restrict__ idx_c,
+                                                   float* __restrict__ sim_c) {
+    __shared__ uint64_t scratch[4];
+    const int q = blockIdx.x;
+    const bool second = blockIdx.y == 1;
+    const uint64_t best = block_max_u64((second ? cand_c : cand_a) + (int64_t)q * stride, n_cand, scratch);
+    if (threadIdx.x == 0) {
+        (second ? idx_c : idx_a)[q] = comp_row(best);
+        (second ? sim_c : sim_a)[q] = comp_sim(best);
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1613,7 +1497,6 @@ struct cslam_pool {
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, fault;
-    unsigned* ticket = nullptr;  // block ticket of the in-launch finish (k_scan_dma), zero at rest
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
@@ -1662,7 +1545,9 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     CSLAM_HIP_TRY(hipMemsetAsync(nrows + p->n * p->xs, 0,
                                  (size_t)(ncap - p->n) * p->xs * sizeof(float), st));
     CSLAM_HIP_TRY(hipMemsetAsync(nnorm + p->n, 0, (size_t)(ncap - p->n) * sizeof(float), st));
-    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    // scans on other streams (the sharded step appends on its exchange stream) may still read
+    // the old buffers: a growth waits for the whole device (rare: capacities double)
+    CSLAM_HIP_TRY(hipDeviceSynchronize());
     if (p->rows) CSLAM_HIP_TRY(hipFree(p->rows));
     if (p->inv_norm) CSLAM_HIP_TRY(hipFree(p->inv_norm));
     p->rows = nrows;
@@ -1722,7 +1607,7 @@ bool dma_scan_applies(const cslam_pool* p) {
 int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
                     int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride,
                     int64_t* n_panels_out, hipStream_t st, float* rnq_out = nullptr,
-                    const BestFinish* finish = nullptr) {
+                    int64_t split = -1, uint64_t* cand_c = nullptr) {
     constexpr int NS = 8, NW = 4, NST = 2;
     const int64_t nw = (int64_t)p->cus * NW;
     int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
@@ -1732,12 +1617,11 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
     if (best && cand_stride < n_panels) return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
     const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
-    // behind the rings: block ticket + the waves' composites of the in-launch finish
-    const size_t lds = (size_t)NW * NST * kDmaStageB + 16 + 2 * NW * 16 * sizeof(uint64_t);
-    BestFinish fin;
-    if (finish) fin = *finish;
-    fin.n_waves = (int)((n_panels + ppw - 1) / ppw);
-    if (fin.cand_c == nullptr) fin.split = INT64_MAX;
+    const size_t lds = (size_t)NW * NST * kDmaStageB;
+    if (cand_c == nullptr || split < 0) {
+        split = INT64_MAX;  // one window
+        cand_c = nullptr;
+    }
     // pool rows are read once per search: non-temporal unless the pool could stay resident
     // in the 256-MiB Infinity Cache between searches
     const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
@@ -1753,7 +1637,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
         hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST>), dim3(blocks), dim3(NW * 64), lds, \
                            st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride, q_rows, \
                            m, dots, dots_stride, (int)n_panels, (int)ppw, p->inv_norm + p->v0,    \
-                           (uint32_t)p->v0, cand, cand_stride, rnq_out, fin);                     \
+                           (uint32_t)p->v0, cand, cand_stride, rnq_out, split, cand_c);           \
     } while (0)
     if (best) {
         if (nt) {
@@ -1774,7 +1658,8 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     }
 #undef CSLAM_DMA_LAUNCH
     CSLAM_HIP_TRY(hipGetLastError());
-    *n_panels_out = best ? fin.n_waves : n_panels;  // BEST: candidates per query (one per wave)
+    // BEST: candidates per query = waves that hold panels
+    *n_panels_out = best ? (n_panels + ppw - 1) / ppw : n_panels;
     return CSLAM_OK;
 }
 
@@ -2098,14 +1983,23 @@ int select_any_k(cslam_pool* p, const float* sims, int64_t sims_stride, int m, i
     return CSLAM_OK;
 }
 
-// search_best (lcsm.py:49,69) of <= 16 queries over the row window [v0, v0+vn): ONE launch of
-// the LDS-DMA scan with the finish inside it (BestFinish).  split >= 0 (window-relative row):
-// also the best row at or behind `split` (idx_c / sim_c) — the sharded step's "best old row /
-// best row of the block just appended" in one pass.  CSLAM_BEST_FINISH=0 keeps the scan + select
-// pair of launches (A/B runs).  Queries are read in place when they need no padding.
-int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
-              int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {
-    static const bool fused_finish = !(getenv("CSLAM_BEST_FINISH") && atoi(getenv("CSLAM_BEST_FINISH")) == 0);
+int append_rows_dev(cslam_pool* p, const float* rows_dev, int64_t n_rows, int64_t row_stride,
+                    hipStream_t st) {
+    CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(rows_dev) & 15) == 0 && (row_stride & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
+                       row_stride, p->dim, p->rows, p->xs, p->dp, p->n, n_rows, p->inv_norm, vec_ok);
+    CSLAM_HIP_TRY(hipGetLastError());
+    p->n += n_rows;
+    return CSLAM_OK;
+}
+
+// search_best (lcsm.py:49,69) of <= 16 queries over the row window [v0, v0+vn): the LDS-DMA scan
+// with the fused arg-max epilogue; leaves one composite per query and wave in cand_a (and, with
+// split >= 0 (window-relative row), the rows at or behind `split` apart in cand_c).  Queries are
+// read in place when they need no padding.
+int best_scan_candidates(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
+                         int64_t* stride_out, int64_t* n_cand_out, hipStream_t st) {
     const bool direct = p->dim == p->dp && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 &&
                         (q_stride & 3) == 0;
     const float* qsrc = q_dev;
@@ -2126,33 +2020,29 @@ int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_
     const int64_t cstride = ((int64_t)p->cus * 4 * ((p->vn + (int64_t)p->cus * 4 * 128 - 1) /
                                                     ((int64_t)p->cus * 4 * 128)) + 63) / 64 * 64;
     CSLAM_TRY(p->cand_a.reserve((size_t)16 * cstride * sizeof(uint64_t)));
-    BestFinish fin;
-    if (split >= 0) {
-        CSLAM_TRY(p->cand_c.reserve((size_t)16 * cstride * sizeof(uint64_t)));
-        fin.cand_c = p->cand_c.as<uint64_t>();
-        fin.split = split;
-    }
-    if (fused_finish) {
-        fin.ticket = p->ticket;
-        fin.idx_a = idx_a;
-        fin.sim_a = sim_a;
-        fin.idx_c = idx_c;
-        fin.sim_c = sim_c;
-    }
+    if (split >= 0) CSLAM_TRY(p->cand_c.reserve((size_t)16 * cstride * sizeof(uint64_t)));
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    int64_t n_cand = 0;
     CSLAM_TRY(launch_scan_dma(p, qsrc, qs, q_rows, m, nullptr, 0, true, p->cand_a.as<uint64_t>(),
-                              cstride, &n_cand, st, nullptr, &fin));
+                              cstride, n_cand_out, st, nullptr, split,
+                              split >= 0 ? p->cand_c.as<uint64_t>() : nullptr));
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
         p->prof_n++;
     }
-    if (fused_finish) return CSLAM_OK;
-    CSLAM_TRY(select_from_candidates(p, &p->cand_a, &p->cand_b, n_cand, cstride, m, 1, idx_a, sim_a, st));
-    if (split >= 0)
-        CSLAM_TRY(select_from_candidates(p, &p->cand_c, &p->cand_b, n_cand, cstride, m, 1, idx_c,
-                                         sim_c, st));
+    *stride_out = cstride;
+    return CSLAM_OK;
+}
+
+// ... and the final level: (row, similarity) per query, for both windows of a split search
+int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
+              int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {
+    int64_t cstride = 0, n_cand = 0;
+    CSLAM_TRY(best_scan_candidates(p, q_dev, q_stride, m, split, &cstride, &n_cand, st));
+    hipLaunchKernelGGL(k_best_pair, dim3(m, split >= 0 ? 2 : 1), dim3(256), 0, st,
+                       p->cand_a.as<uint64_t>(), p->cand_c.as<uint64_t>(), cstride, n_cand, idx_a,
+                       sim_a, idx_c, sim_c);
+    CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
 
@@ -2229,12 +2119,6 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
         return fail(CSLAM_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
     }
     rc = pool_grow(p, capacity_hint > 0 ? capacity_hint : 1000, p->stream);
-    if (rc == CSLAM_OK) {
-        e = hipMalloc(reinterpret_cast<void**>(&p->ticket), 64);
-        if (e == hipSuccess) e = hipMemsetAsync(p->ticket, 0, 64, p->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-        if (e != hipSuccess) rc = fail(CSLAM_E_HIP, "pool_create: %s", hipGetErrorString(e));
-    }
     if (rc != CSLAM_OK) {
         cslam_pool_destroy(p);
         return rc;
@@ -2258,7 +2142,6 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_a.release();
     p->cand_b.release();
     p->cand_c.release();
-    if (p->ticket) (void)hipFree(p->ticket);
     p->comp.release();
     p->fault.release();
     p->h_q.release();
@@ -2307,12 +2190,7 @@ int cslam_pool_add_dev(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, i
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     CSLAM_TRY(order_after_dev(p, st));
-    CSLAM_TRY(pool_grow(p, p->n + n_rows, st));
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(rows_dev) & 15) == 0 && (row_stride & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rows_dev,
-                       row_stride, p->dim, p->rows, p->xs, p->dp, p->n, n_rows, p->inv_norm, vec_ok);
-    CSLAM_HIP_TRY(hipGetLastError());
-    p->n += n_rows;
+    CSLAM_TRY(append_rows_dev(p, rows_dev, n_rows, row_stride, st));
     return mark_dev(p, st);
 }
 
@@ -2384,10 +2262,11 @@ int cslam_pool_search_range_dev(cslam_pool_t* p, const float* queries_dev, int64
 }
 
 int cslam_pool_search_best_split_dev(cslam_pool_t* p, const float* queries_dev, int64_t query_stride,
-                                     int n_queries, int64_t split_row, int32_t* idx_a_dev,
-                                     float* sim_a_dev, int32_t* idx_c_dev, float* sim_c_dev,
-                                     void* stream) {
-    if (!p || n_queries < 0 || split_row < 0 || split_row > p->n ||
+                                     int n_queries, int64_t split_row, int64_t row_hi,
+                                     int32_t* idx_a_dev, float* sim_a_dev, int32_t* idx_c_dev,
+                                     float* sim_c_dev, void* stream) {
+    if (p && row_hi < 0) row_hi = p->n;
+    if (!p || n_queries < 0 || split_row < 0 || split_row > row_hi || row_hi > p->n ||
         (n_queries > 0 && (!queries_dev || query_stride < p->dim || !idx_a_dev || !sim_a_dev ||
                            !idx_c_dev || !sim_c_dev)))
         return fail(CSLAM_E_INVALID, "pool_search_best_split_dev: bad args");
@@ -2396,13 +2275,13 @@ int cslam_pool_search_best_split_dev(cslam_pool_t* p, const float* queries_dev, 
     hipStream_t st = (hipStream_t)stream;  // NULL = the default (null) stream
     CSLAM_TRY(order_after_dev(p, st));
     p->v0 = 0;
-    p->vn = p->n;
-    if (p->n > 0 && split_row > 0 && split_row < p->n && dma_scan_applies(p)) {
+    p->vn = row_hi;
+    if (split_row > 0 && split_row < row_hi && dma_scan_applies(p)) {
         // one scan launch per 16 queries answers both sides
         for (int q0 = 0; q0 < n_queries; q0 += 16) {
             const int mb = n_queries - q0 < 16 ? n_queries - q0 : 16;
             p->v0 = 0;
-            p->vn = p->n;
+            p->vn = row_hi;
             CSLAM_TRY(best_scan(p, queries_dev + (int64_t)q0 * query_stride, query_stride, mb,
                                 split_row, idx_a_dev + q0, sim_a_dev + q0, idx_c_dev + q0,
                                 sim_c_dev + q0, st));
@@ -2411,7 +2290,7 @@ int cslam_pool_search_best_split_dev(cslam_pool_t* p, const float* queries_dev, 
         CSLAM_TRY(search_dev_impl(p, queries_dev, query_stride, n_queries, 1, idx_a_dev, sim_a_dev, st,
                                   0, split_row));
         CSLAM_TRY(search_dev_impl(p, queries_dev, query_stride, n_queries, 1, idx_c_dev, sim_c_dev, st,
-                                  split_row, p->n));
+                                  split_row, row_hi));
     }
     return mark_dev(p, st);
 }
@@ -2509,3 +2388,43 @@ int cslam_pool_profile_end(cslam_pool_t* p, double* avg_scan_ms, int* n_launches
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// internal (not ABI, csrc/shard.hip): the scan half of the split best-match search of <= 16
+// queries over rows [0, row_hi) — stops at one composite per query, window and wave, so that
+// the caller's own kernel can reduce them and go on (match records) in the same launch.
+// *applied = false (nothing launched) where the LDS-DMA scan does not run.
+// ---------------------------------------------------------------------------------------------
+namespace cslam {
+int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64_t row_stride,
+                   hipStream_t st) {
+    if (!p || (!rows_dev && n_rows > 0) || n_rows < 0 || row_stride < (p ? p->dim : 0))
+        return fail(CSLAM_E_INVALID, "pool_append_on: bad args");
+    if (n_rows == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    return append_rows_dev(p, rows_dev, n_rows, row_stride, st);
+}
+int pool_order_on(cslam_pool_t* p, hipStream_t st) {
+    if (!p) return fail(CSLAM_E_INVALID, "pool_order_on: null");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    return mark_dev(p, st);
+}
+int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
+                               int64_t split_row, int64_t row_hi, hipStream_t st,
+                               BestCandidates* out, bool* applied) {
+    *applied = false;
+    if (!p || m < 1 || m > 16 || split_row <= 0 || split_row >= row_hi || row_hi > p->n ||
+        !queries_dev || query_stride < p->dim)
+        return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    p->v0 = 0;
+    p->vn = row_hi;
+    if (!dma_scan_applies(p)) return CSLAM_OK;
+    CSLAM_TRY(order_after_dev(p, st));
+    CSLAM_TRY(best_scan_candidates(p, queries_dev, query_stride, m, split_row, &out->stride, &out->n, st));
+    out->a = p->cand_a.as<uint64_t>();
+    out->c = p->cand_c.as<uint64_t>();
+    *applied = true;
+    return mark_dev(p, st);
+}
+}  // namespace cslam

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "composite.hpp"
 
 using namespace cslam;
 
@@ -148,6 +149,57 @@ __global__ __launch_bounds__(256) void k_make_records(
     recs[3 * (int64_t)i + 2] = r2;
 }
 
+// Split best-match mode, final level and records in ONE launch behind the scan: block i reduces
+// the waves' composites of gathered descriptor i (best old row, best row of the new block) and
+// its first thread writes the two inter-robot record slots exactly like k_make_records<false>.
+__global__ __launch_bounds__(256) void k_records_from_candidates(
+    int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
+    int32_t* __restrict__ kf_of_row, int b_own, double thr, const uint64_t* __restrict__ cand_a,
+    const uint64_t* __restrict__ cand_c, int64_t cand_stride, int64_t n_cand,
+    cslam_match_record_t* __restrict__ recs) {
+    __shared__ uint64_t scratch[4];
+    const int i = blockIdx.x;
+    const uint64_t ba = block_max_u64(cand_a + (int64_t)i * cand_stride, n_cand, scratch);
+    const uint64_t bc = block_max_u64(cand_c + (int64_t)i * cand_stride, n_cand, scratch);
+    if (threadIdx.x != 0) return;
+    const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
+    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
+    auto kf_at = [&](int32_t row) {
+        return row >= n0 ? (int32_t)own_meta[1 + (row - n0)] : kf_of_row[row];
+    };
+    const int s = i / b_max, j = i % b_max;
+    const int64_t* meta = all_meta + (int64_t)s * (1 + b_max);
+    cslam_match_record_t none;
+    none.robot0_id = -1;
+    none.robot0_keyframe_id = 0;
+    none.robot1_id = 0;
+    none.robot1_keyframe_id = 0;
+    none.weight = 0.f;
+    cslam_match_record_t r0 = none, r1 = none;
+    if (j < (int)meta[0] && s != me) {
+        const int32_t kf_s = (int32_t)meta[1 + j];
+        const int32_t ia = comp_row(ba), ic = comp_row(bc);
+        const float sa = comp_sim(ba), sc = comp_sim(bc);
+        if (ia >= 0 && (double)sa >= thr) {  // lcsm.py:69-75
+            r0.robot0_id = me;
+            r0.robot0_keyframe_id = kf_at(ia);
+            r0.robot1_id = s;
+            r0.robot1_keyframe_id = kf_s;
+            r0.weight = sa;
+        }
+        if (ic >= 0 && (double)sc >= thr && !(ia >= 0 && sa >= sc)) {  // lcsm.py:47-55, on the peer's behalf
+            r1.robot0_id = s;
+            r1.robot0_keyframe_id = kf_s;
+            r1.robot1_id = me;
+            r1.robot1_keyframe_id = kf_at(ic);
+            r1.weight = sc;
+        }
+    }
+    recs[3 * (int64_t)i + 0] = r0;
+    recs[3 * (int64_t)i + 1] = r1;
+    recs[3 * (int64_t)i + 2] = none;
+}
+
 __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -165,6 +217,7 @@ struct Slot {
     cslam_match_record_t* recs_host = nullptr;    // pinned copy
     hipEvent_t ev_src = nullptr, ev_pub = nullptr, ev_match = nullptr, ev_done = nullptr;
     int b = 0;
+    int64_t n0 = 0;   // pool rows before this step's own block (appended at publish time)
     int64_t step = -1;
     int state = 0;  // 0 free, 1 published, 2 matched
 };
@@ -206,7 +259,8 @@ int ensure_kf_capacity(cslam_shard* sh, int64_t want, hipStream_t st) {
     if (sh->kf_of_row) {
         CSLAM_HIP_TRY(hipMemcpyAsync(nk, sh->kf_of_row, (size_t)sh->kf_cap * sizeof(int32_t),
                                      hipMemcpyDeviceToDevice, st));
-        CSLAM_HIP_TRY(hipStreamSynchronize(st));
+        // record kernels of earlier steps may still read the old table on another stream
+        CSLAM_HIP_TRY(hipDeviceSynchronize());
         CSLAM_HIP_TRY(hipFree(sh->kf_of_row));
     } else {
         CSLAM_HIP_TRY(hipStreamSynchronize(st));
@@ -357,6 +411,14 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
     hipLaunchKernelGGL(k_pack_block, dim3((unsigned)((bm + 3) / 4)), dim3(256), 0, ps, new_rows_dev,
                        row_stride, b, bm, dim, my_rows);
     CSLAM_HIP_TRY(hipGetLastError());
+    // The own block enters the pool HERE, on the exchange stream, not in front of the scan on the
+    // compute stream: scans in flight read rows below their own window only, and match() works on
+    // the explicit windows [0, n0) / [n0, n0 + b) recorded now.
+    s.n0 = cslam_pool_size(sh->pool);
+    if (b > 0) {
+        CSLAM_TRY(pool_append_on(sh->pool, my_rows, b, dim, ps));
+        CSLAM_TRY(ensure_kf_capacity(sh, s.n0 + b, ps));
+    }
     if (R > 1) {
         CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_rows, s.all_rows,
                                        (int64_t)bm * dim * sizeof(float), CSLAM_COMM_OWN_STREAM));
@@ -380,52 +442,60 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     const int R = sh->R, me = sh->me, bm = sh->b_max, dim = sh->dim;
     const int M = R * bm;
     CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
-    const int64_t n0 = cslam_pool_size(sh->pool);
-    const float* my_rows = s.all_rows + (int64_t)me * bm * dim;
+    const int64_t n0 = s.n0, hi = s.n0 + s.b;   // the own block was appended by publish()
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
     const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);
-    if (sh->best2) {
-        // append first, then ONE launch: best row before n0 and best row of the new block
-        if (s.b > 0) {
-            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
-            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
-        }
-        CSLAM_TRY(cslam_pool_search_best_split_dev(sh->pool, s.all_rows, dim, M, n0, s.idx_a, s.sim_a,
-                                                   s.idx_c, s.sim_c, st));
+    if (R == 1 && sh->k_local == 0) {
+        // a single robot without intra-robot matching: nothing to search, keyframe table only
         hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
                            n0, sh->kf_of_row, s.b, sh->thr, nullptr, nullptr, 1, 0, 0, s.idx_a, s.sim_a,
                            s.idx_c, s.sim_c, my_recs);
-    } else if (sh->fused) {
-        // append first, then ONE scan: the sorted top-K (K > b) of every gathered descriptor
-        // holds both its best older row and its best row of the new block
-        if (s.b > 0) {
-            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
-            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
+        CSLAM_TRY(pool_order_on(sh->pool, st));  // later pool calls order behind the append
+    } else if (sh->best2) {
+        // ONE scan launch: best row before n0 and best row of the new block per gathered
+        // descriptor; its candidates are reduced by the record kernel itself
+        BestCandidates bc;
+        bool applied = false;
+        CSLAM_TRY(pool_best_split_candidates(sh->pool, s.all_rows, dim, M, n0, hi, st, &bc, &applied));
+        if (applied) {
+            hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, me, R, bm,
+                               s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, bc.a, bc.c, bc.stride, bc.n,
+                               my_recs);
+        } else {
+            CSLAM_TRY(cslam_pool_search_best_split_dev(sh->pool, s.all_rows, dim, M, n0, hi, s.idx_a,
+                                                       s.sim_a, s.idx_c, s.sim_c, st));
+            hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm,
+                               s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, nullptr, nullptr, 1, 0, 0,
+                               s.idx_a, s.sim_a, s.idx_c, s.sim_c, my_recs);
         }
-        CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows, dim, M, sh->K, s.topk_idx, s.topk_sim, st));
+    } else if (sh->fused) {
+        // ONE scan of rows [0, n0 + b): the sorted top-K (K > b) of every gathered descriptor
+        // holds both its best older row and its best row of the new block
+        CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, M, sh->K, 0, hi, s.topk_idx,
+                                              s.topk_sim, st));
         hipLaunchKernelGGL((k_make_records<true>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
                            n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
                            sh->min_inbetween, nullptr, nullptr, nullptr, nullptr, my_recs);
     } else {
         // bulk blocks: best old row of every FOREIGN descriptor (the own block is skipped: two
-        // calls around it), append, best new row through the row-range search
+        // calls around it), best new row through the row-range search
         hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_a, (int64_t)M, -1);
         hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_c, (int64_t)M, -1);
         const int lo_n = me * bm, hi_first = (me + 1) * bm, hi_n = M - hi_first;
         if (lo_n > 0)
-            CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows, dim, lo_n, 1, s.idx_a, s.sim_a, st));
+            CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, lo_n, 1, 0, n0, s.idx_a,
+                                                  s.sim_a, st));
         if (hi_n > 0)
-            CSLAM_TRY(cslam_pool_search_dev(sh->pool, s.all_rows + (int64_t)hi_first * dim, dim, hi_n,
-                                            1, s.idx_a + hi_first, s.sim_a + hi_first, st));
+            CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows + (int64_t)hi_first * dim, dim,
+                                                  hi_n, 1, 0, n0, s.idx_a + hi_first,
+                                                  s.sim_a + hi_first, st));
         if (s.b > 0) {
-            CSLAM_TRY(cslam_pool_add_dev(sh->pool, my_rows, s.b, dim, st));
-            CSLAM_TRY(ensure_kf_capacity(sh, n0 + s.b, st));
             if (lo_n > 0)
-                CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, lo_n, 1, n0,
-                                                      n0 + s.b, s.idx_c, s.sim_c, st));
+                CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, lo_n, 1, n0, hi,
+                                                      s.idx_c, s.sim_c, st));
             if (hi_n > 0)
                 CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows + (int64_t)hi_first * dim,
-                                                      dim, hi_n, 1, n0, n0 + s.b, s.idx_c + hi_first,
+                                                      dim, hi_n, 1, n0, hi, s.idx_c + hi_first,
                                                       s.sim_c + hi_first, st));
         }
         hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,

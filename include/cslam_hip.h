@@ -93,15 +93,15 @@ int cslam_pool_search_range_dev(cslam_pool_t* pool, const float* queries_dev,
                                 int64_t row_hi, int32_t* out_idx_dev, float* out_sim_dev,
                                 void* stream);
 /* Best match on both sides of a row boundary in ONE pass over the pool: for every query the best
- * row in [0, split_row) → idx_a / sim_a and the best row in [split_row, size) → idx_c / sim_c
- * (-1 / -inf where a side is empty).  The sharded step's two questions — the best OLD row for
+ * row in [0, split_row) → idx_a / sim_a and the best row in [split_row, row_hi) → idx_c / sim_c
+ * (-1 / -inf where a side is empty; row_hi < 0 = the pool size).  The sharded step's two questions — the best OLD row for
  * `add_other_robot_global_descriptor` (cslam/loop_closure_sparse_matching.py:58-76) and the best row
  * of the block appended in this step, which the peer's `add_local_global_descriptor` would have met
  * in its mirror (lcsm.py:37-56).  Results equal two cslam_pool_search_range_dev calls with k = 1. */
 int cslam_pool_search_best_split_dev(cslam_pool_t* pool, const float* queries_dev,
                                      int64_t query_stride, int n_queries, int64_t split_row,
-                                     int32_t* idx_a_dev, float* sim_a_dev, int32_t* idx_c_dev,
-                                     float* sim_c_dev, void* stream);
+                                     int64_t row_hi, int32_t* idx_a_dev, float* sim_a_dev,
+                                     int32_t* idx_c_dev, float* sim_c_dev, void* stream);
 /* Similarities only: sims_dev[q * sims_stride + row] for row < size (all rows, unsorted). */
 int cslam_pool_similarities_dev(cslam_pool_t* pool, const float* queries_dev,
                                 int64_t query_stride, int n_queries, float* sims_dev,

@@ -408,9 +408,8 @@ def test_full_size_properties(gpu):
 ])
 def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     """cslam_pool_search_best_split_dev: best row before `split` and best row from `split` on in
-    one scan launch with the finish inside it (last-arriver reduction) — bit-identical to the
-    oracle on the two row ranges, ties to the lowest row on either side, repeated launches reuse
-    the ticket."""
+    one scan launch — bit-identical to the oracle on the two row ranges, ties to the lowest row on
+    either side."""
     torch = pytest.importorskip("torch")
     import ctypes
     from cslam_amd import _lib
@@ -431,7 +430,7 @@ def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     oc_idx, oc_sim, _ = oracle_knn.search(X[split:], Q, 1)
     for rep in range(3):
         _lib.check(gpu.cslam_pool_search_best_split_dev(
-            pool.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split,
+            pool.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split, -1,
             *[ctypes.c_void_p(t.data_ptr()) for t in out], None))
         torch.cuda.synchronize()
         ia, sa, ic, sc = [t.cpu().numpy() for t in out]
@@ -443,7 +442,19 @@ def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
         assert ic[0] == split
     if split > 40:
         assert ia[m - 1] == 3
-    # the plain search_best on the same handle still agrees (one window, same ticket)
+    # an explicit upper row bound (the sharded step: later blocks are already in the pool)
+    hi = n - 3
+    if split < hi:
+        _lib.check(gpu.cslam_pool_search_best_split_dev(
+            pool.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split, hi,
+            *[ctypes.c_void_p(t.data_ptr()) for t in out], None))
+        torch.cuda.synchronize()
+        ia, sa, ic, sc = [t.cpu().numpy() for t in out]
+        oc_idx, oc_sim, _ = oracle_knn.search(X[split:hi], Q, 1)
+        np.testing.assert_array_equal(ia, oa_idx[:, 0])
+        np.testing.assert_array_equal(ic, oc_idx[:, 0] + split)
+        assert sa.tobytes() == oa_sim[:, 0].tobytes() and sc.tobytes() == oc_sim[:, 0].tobytes()
+    # the plain search_best on the same handle still agrees (one window)
     rows, sims = pool.search_batch(Q[:min(m, 16)], 1)
     o_idx, o_sim, _ = oracle_knn.search(X, Q[:min(m, 16)], 1)
     np.testing.assert_array_equal(rows, o_idx)

@@ -33,6 +33,8 @@ class OracleMatcher(object):
 
     def add_rows(self, block, keyframe_ids):
         if block.shape[0]:
+            if self.rows.shape[0] == 0:
+                self.rows = np.zeros((0, block.shape[1]), np.float32)   # any dim, fixed by the first block
             self.rows = np.vstack([self.rows, block.cpu().numpy()])
             self.keyframes.extend(int(k) for k in keyframe_ids)
 

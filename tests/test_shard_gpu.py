@@ -234,8 +234,8 @@ def test_device_shard_single_robot_and_pipelining(gpu):
 def test_device_shard_split_best_mode(gpu, world, maxb):
     """Inter-robot matching only (nb_best_matches = 0: frontend.enable_intra_robot_loop_closures
     off, the node default) with <= 16 gathered descriptors per step: ONE scan launch per step
-    answers "best old row" and "best row of the block just appended" (split best-match, finish
-    inside the launch).  256-d so the LDS-DMA scan runs; same candidate set as the sequential
+    answers "best old row" and "best row of the block just appended" (split best-match scan, its
+    candidates reduced by the record kernel).  256-d so the LDS-DMA scan runs; same candidate set as the sequential
     reference semantics, identical replicas and record streams."""
     steps, dim = 12, 256
     rs = np.random.RandomState(31 + world)

@@ -1,7 +1,8 @@
 """Device-side cost of the sharded step (csrc/shard.hip) on ONE GPU: robot 0 of R with a loopback
 transport that fills the other ranks' slots with device-to-device copies of its own block (no
 real peer, no RCCL) — what append + one scan (top-(b+k)) + record building cost next to the plain
-16-query search_best step.  Usage: python tools/shard_step_time.py [R] [steps]"""
+16-query search_best step.  Usage: python tools/shard_step_time.py [R] [steps] [nb_best_matches]
+(nb_best_matches = 0, the default: inter-robot matching only → split best-match scan)"""
 import ctypes
 import os
 import sys
@@ -16,6 +17,7 @@ from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+nb_best = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 N, D = 100_000, 4096
 per_rank = 16 // R
 L = _lib.load()
@@ -35,7 +37,7 @@ def loopback(send, recv, nbytes, stream):
 
 cd = CallbackComm(0, R, 0, loopback)
 cr = CallbackComm(0, R, 0, loopback)
-sh = DeviceShard(pool, 0, R, per_rank, 0.0, cd, cr, nb_best_matches=10, intra_min_inbetween=10)
+sh = DeviceShard(pool, 0, R, per_rank, 0.0, cd, cr, nb_best_matches=nb_best, intra_min_inbetween=10)
 blocks = torch.rand((8, per_rank, D), device=dev, generator=g)
 kf = [N]
 pub = [0]
@@ -76,7 +78,7 @@ host[0] = 0.0
 t0 = time.perf_counter()
 recs = run(steps)
 dt = (time.perf_counter() - t0) / (steps + 1)
-print(f"R={R} per_rank={per_rank}: {dt * 1e3:.4f} ms per step ({host[0] / steps * 1e3:.4f} ms of host enqueue time), "
+print(f"R={R} per_rank={per_rank} nb_best_matches={nb_best}: {dt * 1e3:.4f} ms per step ({host[0] / steps * 1e3:.4f} ms of host enqueue time), "
       f"{recs / (steps + 1):.1f} records per step, kernel {L.cslam_pool_scan_kernel(pool.handle).decode()}")
 
 q = torch.rand((16, D), device=dev, generator=g)
