@@ -209,11 +209,16 @@ def main():
                             nb_best_matches=10 if intra else 0, intra_min_inbetween=10)
         blocks = torch.rand((8, per_rank, D), device=dev, generator=g)   # new keyframes, cycled
         next_kf = [N]
+        torch.cuda.synchronize()
+        # new descriptors come from the front end's stream (the VPR network), not from the
+        # matching stream: publish orders the exchange behind THAT stream, the matching stream
+        # carries scans and record kernels only
+        front = torch.cuda.Stream(device=dev)
 
         def publish():
             kfs = list(range(next_kf[0], next_kf[0] + per_rank))
             next_kf[0] += per_rank
-            shard.publish(blocks[state["published"] % 8], kfs, stream)
+            shard.publish(blocks[state["published"] % 8], kfs, front.cuda_stream)
             state["published"] += 1
 
         def step(t):

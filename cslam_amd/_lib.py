@@ -70,6 +70,7 @@ SIGNATURES = {
     "cslam_pool_scan_kernel": (_c.c_char_p, [_vp]),
     "cslam_comm_unique_id": (_c.c_int, [_vp]),
     "cslam_comm_init": (_c.c_int, [_c.c_int, _c.c_int, _vp, _c.c_int, _c.POINTER(_vp)]),
+    "cslam_comm_init_loopback": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.POINTER(_vp)]),
     "cslam_comm_init_custom": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.POINTER(_vp)]),
     "cslam_device_copy": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int]),
     "cslam_comm_destroy": (_c.c_int, [_vp]),

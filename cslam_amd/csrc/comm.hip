@@ -84,6 +84,16 @@ __global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ src
 
 __global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
 
+// loopback transport: the caller's block into every other rank's slot, one launch
+template <class T>
+__global__ __launch_bounds__(256) void k_replicate(const T* __restrict__ send, T* __restrict__ recv,
+                                                   int64_t per_rank, int nranks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_rank) return;
+    T* dst = recv + (int64_t)blockIdx.y * per_rank;
+    if (dst != send) dst[i] = send[i];
+}
+
 }  // namespace
 
 struct cslam_comm {
@@ -160,6 +170,33 @@ int cslam_comm_init_custom(int rank, int nranks, int device_id, cslam_allgather_
     }
     *out = c;
     return CSLAM_OK;
+}
+
+namespace {
+int loopback_allgather(void* user, const void* send_dev, void* recv_dev, int64_t bytes, void* stream) {
+    const int nranks = (int)(intptr_t)user;
+    hipStream_t st = (hipStream_t)stream;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(send_dev) | reinterpret_cast<uintptr_t>(recv_dev) |
+                         (uintptr_t)bytes;
+    if ((al & 15) == 0) {
+        const int64_t n = bytes / 16;
+        hipLaunchKernelGGL((k_replicate<uint4>), dim3((unsigned)((n + 255) / 256), nranks), dim3(256), 0,
+                           st, (const uint4*)send_dev, (uint4*)recv_dev, n, nranks);
+    } else if ((al & 3) == 0) {
+        const int64_t n = bytes / 4;
+        hipLaunchKernelGGL((k_replicate<uint32_t>), dim3((unsigned)((n + 255) / 256), nranks), dim3(256),
+                           0, st, (const uint32_t*)send_dev, (uint32_t*)recv_dev, n, nranks);
+    } else {
+        hipLaunchKernelGGL((k_replicate<uint8_t>), dim3((unsigned)((bytes + 255) / 256), nranks),
+                           dim3(256), 0, st, (const uint8_t*)send_dev, (uint8_t*)recv_dev, bytes, nranks);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}  // namespace
+
+int cslam_comm_init_loopback(int rank, int nranks, int device_id, cslam_comm_t** out) {
+    return cslam_comm_init_custom(rank, nranks, device_id, loopback_allgather,
+                                  (void*)(intptr_t)nranks, out);
 }
 
 int cslam_comm_destroy(cslam_comm_t* c) {

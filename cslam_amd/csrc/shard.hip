@@ -441,7 +441,10 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int R = sh->R, me = sh->me, bm = sh->b_max, dim = sh->dim;
     const int M = R * bm;
-    CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
+    // the exchange was issued a whole step ago: normally it is complete, and then the compute
+    // stream does not need the device-side wait (a cross-stream barrier packet in front of the
+    // scan cost ~10 us of the 17-us gap between two steps, profiles/r02_shard_step_timeline.txt)
+    if (hipEventQuery(s.ev_pub) != hipSuccess) CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
     const int64_t n0 = s.n0, hi = s.n0 + s.b;   // the own block was appended by publish()
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
     const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);

@@ -297,6 +297,22 @@ class CallbackComm(RcclComm):
         self.transport = name
 
 
+class LoopbackComm(RcclComm):
+    """cslam_comm_t whose all-gather replicates the caller's block into every slot with one kernel
+    (cslam_comm_init_loopback): the compute side of the sharded step on ONE GPU, no peers."""
+
+    def __init__(self, rank, nranks, device_id):
+        from . import _lib
+        self._lib = _lib
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._L.cslam_comm_init_loopback(int(rank), int(nranks), int(device_id),
+                                                    ctypes.byref(h)))
+        self.handle = h
+        self.rank, self.world = int(rank), int(nranks)
+        self.transport = "loopback (one GPU, no peers)"
+
+
 class LocalGroup(object):
     """Transport between robot shards that are THREADS of one process sharing one GPU (tests,
     or several small robots per GPU): device-to-device copies around a thread barrier."""

@@ -143,6 +143,11 @@ typedef int (*cslam_allgather_fn)(void* user, const void* send_dev, void* recv_d
                                   int64_t bytes_per_rank, void* stream);
 int cslam_comm_init_custom(int rank, int nranks, int device_id, cslam_allgather_fn allgather,
                            void* user, cslam_comm_t** out);
+/* Loopback transport (measurement on ONE GPU, tools/shard_step_time.py): every all-gather copies
+ * the caller's block into all nranks slots with one small kernel — rank `rank` of `nranks` sees
+ * its own descriptors as everybody's.  No peer, no RCCL: the compute side of the sharded step
+ * with collectives of realistic launch count but no fabric. */
+int cslam_comm_init_loopback(int rank, int nranks, int device_id, cslam_comm_t** out);
 int cslam_comm_destroy(cslam_comm_t* comm);
 int cslam_comm_rank(const cslam_comm_t* comm);
 int cslam_comm_size(const cslam_comm_t* comm);

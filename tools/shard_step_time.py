@@ -1,6 +1,6 @@
-"""Device-side cost of the sharded step (csrc/shard.hip) on ONE GPU: robot 0 of R with a loopback
-transport that fills the other ranks' slots with device-to-device copies of its own block (no
-real peer, no RCCL) — what append + one scan (top-(b+k)) + record building cost next to the plain
+"""Device-side cost of the sharded step (csrc/shard.hip) on ONE GPU: robot 0 of R with the
+library's loopback transport (cslam_comm_init_loopback: one small kernel per all-gather fills the
+other ranks' slots with copies of its own block; no real peer, no RCCL) — what append + one scan (top-(b+k)) + record building cost next to the plain
 16-query search_best step.  Usage: python tools/shard_step_time.py [R] [steps] [nb_best_matches]
 (nb_best_matches = 0, the default: inter-robot matching only → split best-match scan)"""
 import ctypes
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from cslam_amd import _lib  # noqa: E402
-from cslam_amd.multi_robot import CallbackComm, DeviceShard  # noqa: E402
+from cslam_amd.multi_robot import DeviceShard, LoopbackComm  # noqa: E402
 from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -29,22 +29,21 @@ st = torch.cuda.current_stream().cuda_stream
 pool.add_items_device(X.data_ptr(), N, D, items=None, stream=st)
 
 
-def loopback(send, recv, nbytes, stream):
-    for r in range(R):
-        if recv + r * nbytes != send:
-            _lib.check(L.cslam_device_copy(recv + r * nbytes, send, nbytes, 2, stream, 0))
-
-
-cd = CallbackComm(0, R, 0, loopback)
-cr = CallbackComm(0, R, 0, loopback)
+cd = LoopbackComm(0, R, 0)
+cr = LoopbackComm(0, R, 0)
 sh = DeviceShard(pool, 0, R, per_rank, 0.0, cd, cr, nb_best_matches=nb_best, intra_min_inbetween=10)
 blocks = torch.rand((8, per_rank, D), device=dev, generator=g)
 kf = [N]
 pub = [0]
 
 
+# new descriptors come from the front end's stream (VPR), not from the matching stream
+front = torch.cuda.Stream()
+pst = front.cuda_stream if os.environ.get("SHARD_PUBLISH_SAME_STREAM") != "1" else st
+
+
 def publish():
-    sh.publish(blocks[pub[0] % 8], list(range(kf[0], kf[0] + per_rank)), st)
+    sh.publish(blocks[pub[0] % 8], list(range(kf[0], kf[0] + per_rank)), pst)
     kf[0] += per_rank
     pub[0] += 1
 
