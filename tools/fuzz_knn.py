@@ -1,14 +1,21 @@
 """Randomised parity sweep of the HIP kNN against the C oracle (bit-exact similarities and
 indices) over ragged shapes, k values, duplicated / zero / huge-norm rows and incremental adds.
+Every case also runs the split best-match search (cslam_pool_search_best_split_dev: best row before
+/ from a random split, random upper row bound) against the oracle on the two row ranges.
 Not part of the test suite (minutes); run by hand:  python tools/fuzz_knn.py [cases] [seed]"""
+import ctypes
 import os
 import sys
 
 import numpy as np
+import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
+from cslam_amd import _lib  # noqa: E402
 from oracle import knn as oracle_knn  # noqa: E402
+
+L = _lib.load()
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -48,6 +55,26 @@ for c in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH", dict(dim=dim, n=n, m=m, k=k, scale=scale, cut=cut), flush=True)
+    if ok and n >= 2:
+        ms = min(m, 40)
+        hi = int(rs.randint(2, n + 1))
+        split = int(rs.randint(1, hi))
+        qd = torch.from_numpy(q[:ms]).cuda()
+        out = [torch.empty(ms, dtype=torch.int32, device="cuda"), torch.empty(ms, device="cuda"),
+               torch.empty(ms, dtype=torch.int32, device="cuda"), torch.empty(ms, device="cuda")]
+        _lib.check(L.cslam_pool_search_best_split_dev(pool.handle, ctypes.c_void_p(qd.data_ptr()), dim, ms,
+                                                      split, hi, *[ctypes.c_void_p(t.data_ptr()) for t in out],
+                                                      None))
+        torch.cuda.synchronize()
+        ia, sa, ic, sc = [t.cpu().numpy() for t in out]
+        oa_i, oa_s, _ = oracle_knn.search(x[:split], q[:ms], 1)
+        oc_i, oc_s, _ = oracle_knn.search(x[split:hi], q[:ms], 1)
+        ok2 = np.array_equal(ia, oa_i[:, 0]) and np.array_equal(ic, oc_i[:, 0] + split) and \
+            np.array_equal(sa.view(np.uint32), oa_s[:, 0].view(np.uint32)) and \
+            np.array_equal(sc.view(np.uint32), oc_s[:, 0].view(np.uint32))
+        if not ok2:
+            bad += 1
+            print("SPLIT MISMATCH", dict(dim=dim, n=n, m=ms, split=split, hi=hi, scale=scale), flush=True)
     pool.close()
     if c % 25 == 0:
         print(f"case {c}/{cases} ok so far: {c + 1 - bad}", flush=True)
