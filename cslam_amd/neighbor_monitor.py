@@ -1,44 +1,58 @@
-"""Heartbeat-based liveness of one other robot — mirror of cslam/neighbor_monitor.py:4-53."""
-from time import time
+"""Liveness of ONE other robot, judged from its heartbeat topic.
+
+Behavioural twin of cslam/neighbor_monitor.py:4-53 (same attributes, topic name and truth table,
+pinned by tests/golden/gdlcd_ref.json); written around an explicit little state machine:
+
+    silent ──first beat──▶ warming up ──init delay over──▶ alive ◀──▶ stale (no beat for max delay)
+"""
+import time
 
 from .ros_compat import UInt32
 
+HEARTBEAT_TOPIC = "/r{rid}/cslam/heartbeat"
+_QUEUE_DEPTH = 10
 
-class NeighborMonitor():
-    """Monitors if a neighboring robot is in range"""
+
+class NeighborMonitor(object):
+    # bookkeeping of the publication path (NeighborManager reads and advances these)
+    last_keyframe_received = -1
+    last_keyframe_sent = -1
+    last_match_sent = -1
 
     def __init__(self, node, rid, is_enabled, init_delay_sec, max_delay_sec):
-        self.node = node
-        self.robot_id = rid
+        now = time.time()
+        self.node, self.robot_id = node, rid
         self.is_enabled = is_enabled
-        self.origin_robot_id = self.robot_id
-        self.init_delay_sec = init_delay_sec
-        self.max_delay_sec = max_delay_sec
-        self.first_heartbeat_received = False
-        self.init_time = time()
-        self.latest_time_stamp = self.init_time
-        self.last_keyframe_received = -1
-        self.last_keyframe_sent = -1
-        self.last_match_sent = -1
-        self.heartbeat_subscriber = self.node.create_subscription(
-            UInt32, '/r' + str(rid) + '/' + 'cslam/heartbeat', self.heartbeat_callback, 10)
+        self.init_delay_sec, self.max_delay_sec = init_delay_sec, max_delay_sec
+        self.origin_robot_id = rid              # until the robot says otherwise
+        self.first_heartbeat_received = False   # state "silent"
+        self.init_time = self.latest_time_stamp = now
+        self.last_keyframe_received = self.last_keyframe_sent = self.last_match_sent = -1
+        self.heartbeat_subscriber = node.create_subscription(
+            UInt32, HEARTBEAT_TOPIC.format(rid=rid), self.heartbeat_callback, _QUEUE_DEPTH)
 
     def heartbeat_callback(self, msg):
-        """The other robot is alive; `msg.data` is the id of its pose-graph origin."""
+        """A beat carries the id of the sender's pose-graph origin.  The FIRST beat restarts the
+        warm-up clock (neighbor_monitor.py:33-35)."""
+        stamp = time.time()
         self.origin_robot_id = msg.data
-        self.latest_time_stamp = time()
+        self.latest_time_stamp = stamp
         if not self.first_heartbeat_received:
             self.first_heartbeat_received = True
-            self.init_time = time()
+            self.init_time = time.time()
+
+    def _warmed_up(self, now):
+        return now - self.init_time > self.init_delay_sec
+
+    def _fresh(self, now):
+        return now - self.latest_time_stamp < self.max_delay_sec
 
     def is_alive(self):
-        """True once a heartbeat was seen, the init delay has elapsed and the last beat is
-        recent.  With monitoring disabled the reference falls through a bare `True`
-        expression and returns None (neighbor_monitor.py:52-53) — falsy; kept, because
-        callers rely on truthiness only and the behaviour is part of the surface."""
-        if self.is_enabled:
-            now = time()
-            return (self.first_heartbeat_received
-                    and now - self.init_time > self.init_delay_sec
-                    and now - self.latest_time_stamp < self.max_delay_sec)
-        return None
+        """Truthy iff a beat was seen, the warm-up is over and the last beat is recent.  With
+        monitoring DISABLED the reference evaluates a bare `True` expression and falls off the
+        end (neighbor_monitor.py:52-53): the result is None, i.e. falsy.  Callers only test
+        truthiness, and the golden traces contain that behaviour, so it is kept."""
+        if not self.is_enabled:
+            return None
+        now = time.time()
+        return self.first_heartbeat_received and self._warmed_up(now) and self._fresh(now)

@@ -692,9 +692,36 @@ def gen_cfg4():
                              for k, v in out.items()})
 
 
+def gen_misc():
+    """List helpers of the publication path (cslam/utils/misc.py:6-32) on seeded random inputs,
+    incl. empty lists, starts outside the list and crossed clamp bounds."""
+    from sortedcontainers import SortedDict
+    from cslam.utils import misc as ref
+    rs = random.Random(5)
+    cases = []
+    for _ in range(400):
+        n = rs.randint(0, 12)
+        l = [rs.randint(0, 99) for _ in range(n)]
+        start, chunk = rs.randint(-3, 15), rs.randint(1, 5)
+        keys = sorted({rs.randint(0, 30) for _ in range(n)})
+        d = SortedDict({k: rs.randint(0, 99) for k in keys})
+        a, b, c = rs.randint(-5, 5), rs.randint(-5, 5), rs.randint(-5, 5)
+        cases.append({"list": l, "start": start, "chunk": chunk,
+                      "dict": [[k, d[k]] for k in d.keys()],
+                      "clamp_args": [a, b, c], "clamp": ref.clamp(a, b, c),
+                      "list_clamp": ref.list_clamp(l, start) if n else None,
+                      "list_range": ref.list_range(l, start),
+                      "list_chunks": ref.list_chunks(l, start, chunk),
+                      "dict_to_list_chunks": ref.dict_to_list_chunks(d, start, chunk)})
+    with open(os.path.join(OUT, "misc_ref.json"), "w") as f:
+        json.dump(cases, f)
+    print("misc_ref.json:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     random.seed(0)
     np.random.seed(0)
+    gen_misc()
     gen_knn()
     gen_mac()
     gen_acm()

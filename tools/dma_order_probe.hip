@@ -70,6 +70,52 @@ __global__ __launch_bounds__(NW * 64) void k_stream(const float* __restrict__ X,
     if (sink && lane == 0 && w == 0) sink[0] = *reinterpret_cast<float*>(ring);
 }
 
+// Half stages: 16 rows x 128 floats per stage = 8 DMA instructions of TWO rows x 512 B each
+// (lanes 0-31 one row, lanes 32-63 the next; the odd row's 16-B segments XOR-1 swizzled on the
+// source side as a conflict-free LDS image would need), ring of NST slots of 8 x 1056 B.  Same
+// bytes in the LDS as 2 whole stages with NST = 4, but a slot is half as long in the consumer's
+// hands.  Order: strip-major inside a panel slice: (kc, strip, half).
+template <int NW, int NST, int AUX>
+__global__ __launch_bounds__(NW * 64) void k_stream_half(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
+                                                         int S, int total_waves, float* sink, int d1, int d2) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int kHalfB = 8 * kPieceB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * NW + wave;
+    char* ring = lds + wave * NST * kHalfB;
+    const int nkc = dp >> 8;
+    const int64_t strips = n / 16;
+    const int sub = lane >> 5;                       // which row of the pair
+    const int seg = (lane & 31) ^ sub;               // XOR-1 swizzle for the odd row
+    int slot = 0, issued = 0;
+    auto stage = [&](int64_t strip, int kc, int h) {
+        const float* src = X + (strip * 16 + sub) * xs + kc * 256 + h * 128 + seg * 4;
+        char* sp = ring + slot * kHalfB;
+        if (issued >= NST) {
+            if (NST == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        for (int t = 0; t < d1; ++t) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * j * xs),
+                                             (__attribute__((address_space(3))) void*)(sp + j * kPieceB), 16, 0, AUX);
+        for (int t = 0; t < d2; ++t) __builtin_amdgcn_s_sleep(1);
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        ++issued;
+    };
+    const int64_t s_lo = strips * w / total_waves, s_hi = strips * (w + 1) / total_waves;
+    for (int64_t p0 = s_lo; p0 < s_hi; p0 += S) {
+        const int64_t p1 = p0 + S < s_hi ? p0 + S : s_hi;
+        for (int kc = 0; kc < nkc; ++kc)
+            for (int64_t s = p0; s < p1; ++s)
+                for (int h = 0; h < 2; ++h) stage(s, kc, h);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sink && lane == 0 && w == 0) sink[0] = *reinterpret_cast<float*>(ring);
+}
+
 __global__ void k_fill(float* X, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) X[i] = (float)((i * 2654435761ull) & 0xFFFF) * 1e-5f;
@@ -97,6 +143,31 @@ void run(const char* name, const float* X, int64_t n, int dp, int S, int P, int 
     const double bytes = (double)n * dp * 4;
     printf("%-44s d1=%d d2=%d NW=%d NST=%d AUX=%d S=%d P=%d mode=%d  best %.4f ms avg %.4f ms  %.0f GB/s (best) %.0f (avg)\n", name, d1, d2, NW, NST,
            AUX, S, P, mode, best, sum / reps, bytes / best / 1e6, bytes / (sum / reps) / 1e6);
+    fflush(stdout);
+}
+
+template <int NW, int NST, int AUX>
+void run_half(const char* name, const float* X, int64_t n, int dp, int S, int cus, float* sink, int d1, int d2) {
+    const size_t lds = (size_t)NW * NST * 8 * kPieceB;
+    CK(hipFuncSetAttribute((const void*)k_stream_half<NW, NST, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f, sum = 0.f;
+    const int reps = 12;
+    for (int i = 0; i < reps + 3; ++i) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_stream_half<NW, NST, AUX>), dim3(cus), dim3(NW * 64), lds, 0, X, (int64_t)dp, n, dp, S,
+                           cus * NW, sink, d1, d2);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 3) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double bytes = (double)n * dp * 4;
+    printf("%-44s d1=%d d2=%d NW=%d NST=%d AUX=%d S=%d half stages  best %.4f ms avg %.4f ms  %.0f GB/s (best) %.0f (avg)\n", name,
+           d1, d2, NW, NST, AUX, S, best, sum / reps, bytes / best / 1e6, bytes / (sum / reps) / 1e6);
     fflush(stdout);
 }
 
@@ -140,5 +211,13 @@ int main() {
     run<4, 2, 2>("nt, gap 1024 + mfma 3072", X, n, dp, 8, 1, 0, cus, sink, 16, 48);
     run<3, 3, 2>("3w3s nt, gap 512 + mfma 2048", X, n, dp, 8, 1, 0, cus, sink, 8, 32);
     run<3, 3, 2>("3w3s nt, gap 1024 + mfma 3072", X, n, dp, 8, 1, 0, cus, sink, 16, 48);
+    // half stages (two rows per DMA instruction), 4 slots per wave: same LDS, finer hand-over
+    run_half<4, 4, 2>("half stages x4 nt", X, n, dp, 8, cus, sink, 0, 0);
+    run_half<4, 4, 2>("half stages x4 nt, gap 256 + mfma 1024", X, n, dp, 8, cus, sink, 4, 16);
+    run_half<4, 4, 2>("half stages x4 nt, gap 384 + mfma 1024", X, n, dp, 8, cus, sink, 6, 16);
+    run_half<4, 2, 2>("half stages x2 nt, gap 256 + mfma 1024", X, n, dp, 8, cus, sink, 4, 16);
+    run<4, 2, 2>("whole stages x2 nt, gap 512 + mfma 2048", X, n, dp, 8, 1, 0, cus, sink, 8, 32);
+    run_half<4, 4, 2>("half stages x4 nt, gap 256 + mfma 1024", X, n, dp, 8, cus, sink, 4, 16);
+    run<4, 2, 2>("whole stages x2 nt, gap 512 + mfma 2048", X, n, dp, 8, 1, 0, cus, sink, 8, 32);
     return 0;
 }

@@ -431,12 +431,17 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_ref, dim3((unsigned)((n + 255) / 256), 16), dim3(256), 0, 0, X, (int64_t)dp, n, dp, Q, ref, ds);
     CK(hipDeviceSynchronize());
     printf("n=%lld dp=%d cus=%d\n", (long long)n, dp, cus);
+    // cost decomposition of the shipped structure (NS = 8, 4 waves x 2 stages, nt); MODE bits:
+    // 1 = B loads (queries from L2), 2 = MFMA (else 64 VALU fma), 4 = NO LDS reads of the stage
     for (int round = 0; round < 2; ++round) {
-        run<8, 4, 3, 2, 2>("stage ring 4w x 2 nt", X, n, dp, Q, dots, ref, ds, cus, true);
-        run_pr<7, 4, 38, 2>("piece ring 4w x 38 nt", X, n, dp, Q, dots, ref, ds, cus);
-        run_pr<7, 4, 32, 2>("piece ring 4w x 32 nt", X, n, dp, Q, dots, ref, ds, cus);
-        run_pr<9, 3, 50, 2>("piece ring 3w x 50 nt", X, n, dp, Q, dots, ref, ds, cus);
-        run<9, 3, 3, 3, 2>("stage ring 3w x 3 nt", X, n, dp, Q, dots, ref, ds, cus, true);
+        run<8, 4, 3, 2, 2>("full: B + LDS reads + MFMA", X, n, dp, Q, dots, ref, ds, cus, round == 0);
+        run<8, 4, 2, 2, 2>("no B loads", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 1, 2, 2>("B + LDS reads + VALU (no MFMA)", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 0, 2, 2>("LDS reads + VALU", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 7, 2, 2>("B + MFMA, no LDS reads", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 6, 2, 2>("MFMA only", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 5, 2, 2>("B + VALU, no LDS reads", X, n, dp, Q, dots, ref, ds, cus, false);
+        run<8, 4, 4, 2, 2>("control structure only (VALU)", X, n, dp, Q, dots, ref, ds, cus, false);
     }
     return 0;
 }
