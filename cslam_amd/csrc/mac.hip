@@ -1027,6 +1027,30 @@ __device__ inline double wave_reverse(double v) {
                             __builtin_amdgcn_ds_bpermute(idx, __double2loint(v)));
 }
 
+// two right-hand sides through one affine recurrence (same multipliers): v_i = m_i v_{i-1} + c_i
+struct Aff2 {
+    double m, c1, c2;
+};
+__device__ inline Aff2 compose2(Aff2 first, Aff2 then) {  // apply `first`, then `then`
+    return Aff2{then.m * first.m, then.m * first.c1 + then.c1, then.m * first.c2 + then.c2};
+}
+__device__ inline Aff2 wave_scan_aff2(Aff2 v) {
+#define CSLAM_SCAN_STEP(CTRL, MASK)                                                      \
+    {                                                                                    \
+        const Aff2 o{dpp_mov<CTRL, MASK>(v.m, 1.0), dpp_mov<CTRL, MASK>(v.c1, 0.0),      \
+                     dpp_mov<CTRL, MASK>(v.c2, 0.0)};                                    \
+        v = compose2(o, v);                                                              \
+    }
+    CSLAM_SCAN_STEP(kDppRowShr + 1, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 2, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 4, 0xF)
+    CSLAM_SCAN_STEP(kDppRowShr + 8, 0xF)
+    CSLAM_SCAN_STEP(kDppRowBcast15, 0xA)
+    CSLAM_SCAN_STEP(kDppRowBcast31, 0xC)
+#undef CSLAM_SCAN_STEP
+    return v;
+}
+
 constexpr int kPT = 512;
 constexpr int kPWaves = kPT / 64;
 constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
@@ -1058,11 +1082,11 @@ struct PArgs {
 };
 
 // slot offsets inside the exchange buffer; every array is [2 parities][...]
-constexpr int kSlotY = 0, kSlotZ = 2 * kPMaxBlocks,  // [2][B]: yloc_e, zA_s of the partitioned solve
-              kSlotCphi = 4 * kPMaxBlocks, kSlotCzf = 5 * kPMaxBlocks,  // [B] each: per-solve constants
+constexpr int kSlotCphi = 4 * kPMaxBlocks, kSlotCzf = 5 * kPMaxBlocks,  // [B] each: per-solve constants
               kSlotCpsi = 6 * kPMaxBlocks, kSlotPs = 8 * kPMaxBlocks, kSlotRp = 10 * kPMaxBlocks,
               kSlotPt = 12 * kPMaxBlocks /* [2][12][kPMaxBlocks] */,
-              kSlotW = 36 * kPMaxBlocks /* [2][wstride] */;
+              kSlotSw = 36 * kPMaxBlocks /* [2][4][kPMaxBlocks]: interface scalars of two sweeps */,
+              kSlotW = 44 * kPMaxBlocks /* [2][wstride] */;
 
 // One buffer_load/store_dwordx4 with sc1 (agent scope: served by / written through to the
 // memory side, past the per-XCD L2) per slot.  Plain buffer intrinsics, not volatile or atomic
@@ -1133,6 +1157,29 @@ __device__ inline void block_scan_p(Aff t, Aff* swave /* [kPWaves] */, Aff& excl
     excl = REV ? Aff{wave_reverse(ex.m), wave_reverse(ex.c)} : ex;
 }
 
+// the same for two right-hand sides at once (one barrier, one pass of multipliers)
+template <bool REV>
+__device__ inline void block_scan_p2(Aff2 t, Aff2* swave /* [kPWaves] */, Aff2& excl, Aff2& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Aff2 v = REV ? Aff2{wave_reverse(t.m), wave_reverse(t.c1), wave_reverse(t.c2)} : t;
+    v = wave_scan_aff2(v);
+    Aff2 ex{dpp_mov<kDppWaveShr1>(v.m, 1.0), dpp_mov<kDppWaveShr1>(v.c1, 0.0),
+            dpp_mov<kDppWaveShr1>(v.c2, 0.0)};
+    if (lane == 63) swave[wave] = v;
+    __syncthreads();
+    Aff2 pre{1.0, 0.0, 0.0};
+    total = Aff2{1.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < kPWaves; ++q) {
+        const int k = REV ? kPWaves - 1 - q : q;
+        const Aff2 sk = swave[k];
+        if (REV ? (k > wave) : (k < wave)) pre = compose2(pre, sk);
+        total = compose2(total, sk);
+    }
+    ex = compose2(pre, ex);
+    excl = REV ? Aff2{wave_reverse(ex.m), wave_reverse(ex.c1), wave_reverse(ex.c2)} : ex;
+}
+
 // sum over workgroups of one published double per workgroup (lane j of the calling wave polls
 // workgroup j; every lane returns the sum)
 __device__ inline double fold_sum(SlotBuf rs, int slot, int nb, double stamp, int& ok) {
@@ -1170,6 +1217,7 @@ __device__ inline double block_sum_p(const double (&v)[NV], double* sred) {
 template <int E>
 __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     __shared__ Aff swave[kPWaves], swave_b[kPWaves];  // forward / backward block scans
+    __shared__ Aff2 swave2[kPWaves], swave2_b[kPWaves];
     __shared__ double sred[12 * kPWaves];
     __shared__ double s_vin, s_res, s_vinb, s_mu, s_g[12];
     __shared__ int s_ovw[kPWaves], s_ov_pos[kPOverflow * kPT], s_ov_own[kPOverflow * kPT];
@@ -1205,7 +1253,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     int ok = 1;
     double res = 0.0;
 
-    double x[E], p[E], Ax[E], Ap[E], r[E], lprev[E], lcur[E], idv[E];
+    double x[E], p[E], Ax[E], Ap[E], lprev[E], lcur[E], idv[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = i0 + e;
@@ -1240,46 +1288,107 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         }
         if (!__syncthreads_and(ok)) done = 4;
     }
-    // ---- partitioned tridiagonal solve (M z = r with M = L D L^T, one exchange round) ---------
+    // ---- partitioned tridiagonal solve (M z = r with M = L D L^T) WITHOUT a round of its own ----
     // Inside workgroup b (nodes s..e) the forward sweep is y_i = yloc_i + phi_i * Y_{s-1} and the
     // backward sweep z_i = zA_i + Y_{s-1} * zF_i + Z_{e+1} * psi_i, where yloc / zA are the sweeps
     // with zero incoming values and
     //   phi_i = prod_{k=s-1}^{i-1} (-l_k),   zF = backward sweep of phi * invd,
     //   psi_i = prod_{k=i}^{e} (-l_k)
-    // depend on the factorisation only.  A workgroup therefore does BOTH local sweeps straight
-    // after the Ritz update and publishes two scalars (yloc_e, zA_s); everybody then folds the
-    // two scalar recurrences  Y_e(b) = yloc_e(b) + phi_e(b) Y_e(b-1)  and
-    // Z_s(b) = zA_s(b) + Y_e(b-1) zF_s(b) + psi_s(b) Z_s(b+1)  with two wave scans and corrects
-    // its nodes — instead of one exchange round per sweep.
+    // depend on the factorisation only; everybody folds the two scalar recurrences
+    //   Y_e(b) = yloc_e(b) + phi_e(b) Y_e(b-1),   Z_s(b) = zA_s(b) + Y_e(b-1) zF_s(b) + psi_s(b) Z_s(b+1)
+    // over the workgroups with two wave scans.  Round 2: the local sweeps are LINEAR in the
+    // right-hand side and r_new = Ax_new - theta x_new is a combination of vectors that follow
+    // three-term recurrences, so the local sweeps (per-node zA and the two interface scalars) of
+    // x, p, Ax, Ap follow the SAME recurrences; only the two new vectors of an iteration, w - mu
+    // and A w, are swept — while the Gram sums are in flight — and their four interface scalars
+    // ride in the Gram round.  As soon as a workgroup knows the Ritz coefficients it knows the
+    // interface values of r_new for every workgroup: two exchange rounds per iteration (w gather,
+    // Gram + sweep scalars) instead of three, and the sweeps are off the critical path.
+    // (numpy prototype on the cfg3 graph: 233 iterations either way, lambda_2 equal to 4e-19.)
+    __shared__ double s_if[8][kPMaxBlocks];   // Y, Z of x, p, Ax, Ap per workgroup (wave 0 keeps them)
+    __shared__ double s_new[4][kPMaxBlocks];  // Y, Z of (w - mu), A w of this iteration
+    constexpr bool kConstInLds = E <= 2;      // zF, psi out of the registers where the LDS has room
+    __shared__ double s_zf[kConstInLds ? kPT * E : 1], s_psi[kConstInLds ? kPT * E : 1];
     Aff tot;
-    double zA[E], phi[E], zF[E], psi[E];
-    auto local_sweeps = [&](double& yloc_e, double& zA_s) {
-        Aff t{1.0, 0.0};
+    double phi[E], zF[E], psi[E];
+    // local backward sweeps of x, p, Ax, Ap (per node): touched twice per iteration (w, Ritz
+    // update) — in the LDS where it has room (2 nodes per thread at 256 VGPRs spilled 128 of them
+    // with these in registers), in registers otherwise
+    __shared__ double s_zs[kConstInLds ? 6 * kPT * E : 1];
+    double zreg[kConstInLds ? 1 : 6 * E];
+    auto zget = [&](int which, int e) -> double {
+        return kConstInLds ? s_zs[(which * E + e) * kPT + tid] : zreg[kConstInLds ? 0 : which * E + e];
+    };
+    auto zset = [&](int which, int e, double v) {
+        if (kConstInLds)
+            s_zs[(which * E + e) * kPT + tid] = v;
+        else
+            zreg[kConstInLds ? 0 : which * E + e] = v;
+    };
+    constexpr int kZx = 0, kZp = 1, kZAx = 2, kZAp = 3, kZw = 4, kZAw = 5;
 #pragma unroll
-        for (int e = 0; e < E; ++e) t = compose(t, Aff{-lprev[e], r[e]});
-        Aff ex;
-        block_scan_p<false>(t, swave, ex, tot);
-        yloc_e = tot.c;
-        double yl[E];
-        double v = ex.c;  // zero incoming value
+    for (int e = 0; e < E; ++e) {
+        zset(kZx, e, 0.0);
+        zset(kZp, e, 0.0);
+        zset(kZAx, e, 0.0);
+        zset(kZAp, e, 0.0);
+    }
+    // local sweeps (zero incoming values) of TWO right-hand sides in one pair of block scans: the
+    // multipliers are the matrix's, shared; per-node backward results go to the z arrays `za`, `zb`,
+    // the interface scalars (forward total, backward total) come back
+    auto local_sweeps2 = [&](const double (&v1)[E], const double (&v2)[E], int za, int zb, double& y1,
+                             double& z1, double& y2, double& z2) {
+        Aff2 t{1.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e) t = compose2(t, Aff2{-lprev[e], v1[e], v2[e]});
+        Aff2 ex, tt;
+        block_scan_p2<false>(t, swave2, ex, tt);
+        y1 = tt.c1;
+        y2 = tt.c2;
+        double yl1[E], yl2[E];
+        double a1 = ex.c1, a2 = ex.c2;  // zero incoming values
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            v = r[e] - lprev[e] * v;
-            yl[e] = v;
+            a1 = v1[e] - lprev[e] * a1;
+            a2 = v2[e] - lprev[e] * a2;
+            yl1[e] = a1;
+            yl2[e] = a2;
         }
-        Aff tb{1.0, 0.0};
+        Aff2 tb{1.0, 0.0, 0.0};
 #pragma unroll
-        for (int e = E - 1; e >= 0; --e) tb = compose(tb, Aff{-lcur[e], yl[e] * idv[e]});
-        block_scan_p<true>(tb, swave_b, ex, tot);
-        zA_s = tot.c;
-        v = ex.c;
+        for (int e = E - 1; e >= 0; --e) tb = compose2(tb, Aff2{-lcur[e], yl1[e] * idv[e], yl2[e] * idv[e]});
+        block_scan_p2<true>(tb, swave2_b, ex, tt);
+        z1 = tt.c1;
+        z2 = tt.c2;
+        a1 = ex.c1;
+        a2 = ex.c2;
 #pragma unroll
         for (int e = E - 1; e >= 0; --e) {
-            v = yl[e] * idv[e] - lcur[e] * v;
-            zA[e] = v;
+            a1 = yl1[e] * idv[e] - lcur[e] * a1;
+            a2 = yl2[e] * idv[e] - lcur[e] * a2;
+            zset(za, e, a1);
+            zset(zb, e, a2);
         }
     };
+    // wave 0, lane j = workgroup j: interface values of r = Ax - theta x from the tables, the two
+    // scalar recurrences over the workgroups, this workgroup's incoming values → s_vin / s_vinb
     double c_phi = 1.0, c_zf = 0.0, c_psi = 1.0;  // wave 0, lane j: constants of workgroup j
+    auto interface_of_r = [&](double th) {
+        const double yr = lane < nb ? s_if[4][lane] - th * s_if[0][lane] : 0.0;
+        const double zr = lane < nb ? s_if[5][lane] - th * s_if[1][lane] : 0.0;
+        // Y_e(j): forward recurrence, ascending j = ascending lanes
+        const Aff fy = wave_scan_aff(Aff{c_phi, yr});
+        const double yin = dpp_mov<kDppWaveShr1>(fy.c, 0.0);      // Y_e(j - 1)
+        // Z_s(j): backward recurrence, descending j = ascending lanes after a reversal
+        const double cz = lane < nb ? zr + yin * c_zf : 0.0;
+        const Aff bz = wave_scan_aff(Aff{wave_reverse(c_psi), wave_reverse(cz)});
+        const double y_b = lane_bcast_dyn(yin, b);
+        const double z_b = b + 1 < nb ? lane_bcast_dyn(bz.c, 63 - (b + 1)) : 0.0;
+        if (lane == 0) {
+            s_vin = y_b;
+            s_vinb = z_b;
+        }
+    };
     if (!done) {
         // constants of this factorisation
         {
@@ -1306,6 +1415,10 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 zF[e] = v;
                 mm = -lcur[e] * mm;
                 psi[e] = mm;
+                if (kConstInLds) {
+                    s_zf[tid * E + e] = v;     // read back by this thread only
+                    s_psi[tid * E + e] = mm;
+                }
             }
             if (tid == 0) {
                 st_slot(xb, kSlotCphi + b, phi_e, stamp0);
@@ -1313,7 +1426,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 st_slot(xb, kSlotCpsi + b, tot.m, stamp0);
             }
         }
-        // bootstrap Rayleigh-Ritz, first residual, its local sweeps
+        // bootstrap Rayleigh-Ritz, first residual, local sweeps of x and Ax
         double g[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) g[q] = 0.0;
@@ -1326,24 +1439,41 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         for (int e = 0; e < E; ++e) {
             x[e] *= coef[0];
             Ax[e] *= coef[0];
-            r[e] = Ax[e] - theta * x[e];
-            rs[0] += fabs(r[e]);
+            rs[0] += fabs(Ax[e] - theta * x[e]);
         }
-        double yloc_e, zA_s;
-        local_sweeps(yloc_e, zA_s);
+        double yx, zxs, yax, zaxs;
+        local_sweeps2(x, Ax, kZx, kZAx, yx, zxs, yax, zaxs);
         const double bs = block_sum_p<1>(rs, sred);
         if (tid == 0 && !done) {
-            st_slot(xb, kSlotY + kPMaxBlocks + b, yloc_e, stamp0 + 1.0);
-            st_slot(xb, kSlotZ + kPMaxBlocks + b, zA_s, stamp0 + 1.0);
+            st_slot(xb, kSlotSw + 0 * kPMaxBlocks + b, yx, stamp0);   // parity 0, stamp0
+            st_slot(xb, kSlotSw + 1 * kPMaxBlocks + b, zxs, stamp0);
+            st_slot(xb, kSlotSw + 2 * kPMaxBlocks + b, yax, stamp0);
+            st_slot(xb, kSlotSw + 3 * kPMaxBlocks + b, zaxs, stamp0);
             st_slot(xb, kSlotRp + kPMaxBlocks + b, bs, stamp0 + 1.0);
         }
-        if (wave == 0 && lane < nb) {   // everybody's constants, once per solve
+        // (a Rayleigh-Ritz breakdown is the same decision in every workgroup: nobody has published)
+        if (done) {
+        } else if (wave == 0 && lane < nb) {   // everybody's constants, once per solve
             d2 v0 = ld_slot(xb, kSlotCphi + lane), v1 = ld_slot(xb, kSlotCzf + lane);
             poll_slots2(xb, kSlotCphi + lane, kSlotCzf + lane, true, v0, v1, stamp0, ok);
             c_phi = v0.x;
             c_zf = v1.x;
             c_psi = poll_slot(xb, kSlotCpsi + lane, ld_slot(xb, kSlotCpsi + lane), stamp0, ok);
+        } else if (wave == 1) {
+            const double v = fold_sum(xb, kSlotRp + kPMaxBlocks, nb, stamp0 + 1.0, ok);
+            if (lane == 0) s_res = v;
+        } else if (wave >= 4 && lane < nb) {
+            // interface tables: rows 0,1 = Y,Z of x; 4,5 = Y,Z of Ax; p and Ap start at zero
+            const int q = wave - 4;
+            const int slot = kSlotSw + q * kPMaxBlocks + lane;
+            const double v = poll_slot(xb, slot, ld_slot(xb, slot), stamp0, ok);
+            s_if[q < 2 ? q : q + 2][lane] = v;
+            s_if[q < 2 ? q + 2 : q + 4][lane] = 0.0;
         }
+        if (!__syncthreads_and(ok)) done = done ? done : 4;
+        if (wave == 0 && !done) interface_of_r(theta);
+        __syncthreads();
+        res = s_res / lnorm;
     }
     // Row i of L(w) = chain terms (weights in registers; w of i-1 / i+1 comes from this thread's
     // own registers or the adjacent lane, and only across a wave boundary from a published
@@ -1437,54 +1567,26 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
     long long plast = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const long long pstart = plast;
 
-    int k = 0;
-    for (; !done; ++k) {
-        const double stamp = stamp0 + 1.0 + (double)k;
-        const int par = (k + 1) & 1;
-        const int xo = par * kPMaxBlocks;
-
-        // ---- A: residual norm + the interface values of the partitioned solve (published by D /
-        //         above): two scalar recurrences over the workgroups, folded by one wave
-        if (wave == 0) {
-            d2 vy{0.0, stamp}, vz{0.0, stamp};
-            if (lane < nb) {
-                vy = ld_slot(xb, kSlotY + xo + lane);
-                vz = ld_slot(xb, kSlotZ + xo + lane);
-                poll_slots2(xb, kSlotY + xo + lane, kSlotZ + xo + lane, true, vy, vz, stamp, ok);
-            }
-            // Y_e(j): forward recurrence, ascending j = ascending lanes
-            const Aff fy = wave_scan_aff(Aff{c_phi, lane < nb ? vy.x : 0.0});
-            const double yin = dpp_mov<kDppWaveShr1>(fy.c, 0.0);      // Y_e(j - 1)
-            // Z_s(j): backward recurrence, descending j = ascending lanes after a reversal
-            const double cz = lane < nb ? vz.x + yin * c_zf : 0.0;
-            const Aff bz = wave_scan_aff(Aff{wave_reverse(c_psi), wave_reverse(cz)});
-            const double y_b = lane_bcast_dyn(yin, b);
-            const double z_b = b + 1 < nb ? lane_bcast_dyn(bz.c, 63 - (b + 1)) : 0.0;
-            if (lane == 0) {
-                s_vin = y_b;
-                s_vinb = z_b;
-            }
-        } else if (wave == 1) {
-            const double v = fold_sum(xb, kSlotRp + xo, nb, stamp, ok);
-            if (lane == 0) s_res = v;
-        }
-        if (!__syncthreads_and(ok)) {
-            done = 4;
-            break;
-        }
-        PTICK(0);
-        // convergence test of the last Ritz update (networkx criterion, see k_rr_solve)
-        res = s_res / lnorm;
+    // convergence test of a Ritz update (networkx criterion, see k_rr_solve); counts the
+    // iteration that follows when there is one
+    auto converged = [&]() {
         if (res < tol)
             done = 1;
         else if (iters >= max_iters)
             done = 3;
         if (!(res == res)) done = 2;
-        if (done) break;
-        iters += 1;
-        PTICK(1);
-        PTICK(2);
-        // w = M^-1 r (published per node where the mat-vec of another thread gathers it)
+        if (!done) iters += 1;
+        return done != 0;
+    };
+    int k = 0;
+    if (!done) converged();  // the bootstrap's residual (a warm start may be there already)
+    for (; !done; ++k) {
+        const double stamp = stamp0 + 1.0 + (double)k;
+        const int par = (k + 1) & 1;
+        const int xo = par * kPMaxBlocks;
+
+        // ---- B: w = M^-1 r from the sweeps kept by recurrence and the interface values (D / the
+        //         bootstrap); published per node where the mat-vec of another thread gathers it
         double w[E];
         const int wslot = kSlotW + par * (int)a.wstride;
         {
@@ -1492,7 +1594,9 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             double ws[1] = {0.0};
 #pragma unroll
             for (int e = E - 1; e >= 0; --e) {
-                const double v = zA[e] + yin * zF[e] + zin * psi[e];
+                const double zf = kConstInLds ? s_zf[tid * E + e] : zF[e];
+                const double ps = kConstInLds ? s_psi[tid * E + e] : psi[e];
+                const double v = (zget(kZAx, e) - theta * zget(kZx, e)) + yin * zf + zin * ps;
                 w[e] = v;
                 ws[0] += v;
                 if (publish[e]) st_slot(xb, wslot + i0 + e, v, stamp);
@@ -1500,7 +1604,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             const double bs = block_sum_p<1>(ws, sred);
             if (tid == 0) st_slot(xb, kSlotPs + xo + b, bs, stamp);
         }
-        PTICK(3);
+        PTICK(0);
 
         // ---- C: Aw = L w (gathering the neighbours' w), Gram partials of S = [x, w - mu, p]
         double Aw[E];
@@ -1527,6 +1631,10 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             if (wave == 0) {
                 const double v = fold_sum(xb, kSlotPs + xo, nb, stamp, ok);
                 if (lane == 0) s_mu = v / (double)n;
+            } else if (wave == 1 && k > 0) {
+                // residual norm of the Ritz update of the previous iteration (published by D)
+                const double v = fold_sum(xb, kSlotRp + xo, nb, stamp, ok);
+                if (lane == 0) s_res = v;
             }
             // wait until every gathered slot carries this iteration's stamp; the stale ones are
             // re-read TOGETHER (one round trip per retry, not one per slot)
@@ -1624,8 +1732,31 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             done = 4;
             break;
         }
-        PTICK(4);
+        PTICK(1);
+        if (k > 0) {
+            // the previous Ritz update's residual norm arrived with this round: x is final if it
+            // has converged (the w and A w just computed are then simply dropped)
+            res = s_res / lnorm;
+            if (converged()) break;
+        }
         const double mu = s_mu;
+        double wc[E];  // w - mu (zero past the last node)
+#pragma unroll
+        for (int e = 0; e < E; ++e) wc[e] = (i0 + e < n) ? w[e] - mu : 0.0;
+        // ---- local sweeps of the two NEW vectors first: their interface
+        //      scalars are published together with the Gram partials (ONE poll point)
+        {
+            double yw, zws, yaw, zaws;
+            local_sweeps2(wc, Aw, kZw, kZAw, yw, zws, yaw, zaws);
+            if (tid == 0) {
+                const int so = kSlotSw + par * 4 * kPMaxBlocks + b;
+                st_slot(xb, so + 0 * kPMaxBlocks, yw, stamp);
+                st_slot(xb, so + 1 * kPMaxBlocks, zws, stamp);
+                st_slot(xb, so + 2 * kPMaxBlocks, yaw, stamp);
+                st_slot(xb, so + 3 * kPMaxBlocks, zaws, stamp);
+            }
+        }
+        PTICK(3);
         {
             double g[12];
 #pragma unroll
@@ -1633,7 +1764,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 if (i0 + e < n) {
-                    const double xi = x[e], wi = w[e] - mu, pi = p[e], acc = Aw[e];
+                    const double xi = x[e], wi = wc[e], pi = p[e], acc = Aw[e];
                     g[0] += xi * xi;
                     g[1] += xi * wi;
                     g[2] += xi * pi;
@@ -1651,27 +1782,31 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             const double bs = block_sum_p<12>(g, sred);
             if (tid < 12) st_slot(xb, kSlotPt + (par * 12 + tid) * kPMaxBlocks + b, bs, stamp);
         }
-        PTICK(5);
+        PTICK(2);
 
-        // ---- D: Gram sums (wave v folds sums v and v + 8), Rayleigh-Ritz in every thread,
-        //         Ritz update, residual, forward composites of the next iteration
+        // ---- D: Gram sums (wave v folds sum v, waves 0-3 also sum v + 8), Rayleigh-Ritz in every
+        //         thread, Ritz update of the vectors AND of their sweeps; only then the sweep scalars
+        //         of the round (published after the Gram partials: their round trip hides behind
+        //         the Rayleigh-Ritz), interface values of the new r
         {
             const int s0 = kSlotPt + (par * 12 + wave) * kPMaxBlocks + lane;
-            const int s1 = s0 + 8 * kPMaxBlocks;
             const bool two = wave < 4;
+            const int s1 = two ? s0 + 8 * kPMaxBlocks
+                               : kSlotSw + (par * 4 + (wave - 4)) * kPMaxBlocks + lane;
             d2 v0{0.0, stamp}, v1{0.0, stamp};
             if (lane < nb) {
                 v0 = ld_slot(xb, s0);
-                if (two) v1 = ld_slot(xb, s1);
+                v1 = ld_slot(xb, s1);
             }
             double g0 = 0.0, g1 = 0.0;
             if (lane < nb) {
-                poll_slots2(xb, s0, s1, two, v0, v1, stamp, ok);
+                poll_slots2(xb, s0, s1, true, v0, v1, stamp, ok);
                 g0 = v0.x;
-                if (two) g1 = v1.x;
+                g1 = v1.x;
+                if (!two) s_new[wave - 4][lane] = g1;
             }
             g0 = wave_sum_dpp(g0);
-            g1 = wave_sum_dpp(g1);
+            if (two) g1 = wave_sum_dpp(g1);
             if (lane == 0) {
                 s_g[wave] = g0;
                 if (two) s_g[wave + 8] = g1;
@@ -1681,7 +1816,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
             done = 4;
             break;
         }
-        PTICK(6);
+        PTICK(4);
         {
             double g[12];
 #pragma unroll
@@ -1691,11 +1826,11 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 done = 2;
                 break;
             }
+            PTICK(5);
             double rs[1] = {0.0};
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const double wi = (i0 + e < n) ? w[e] - mu : 0.0;
-                const double pn = coef[1] * wi + coef[2] * p[e];
+                const double pn = coef[1] * wc[e] + coef[2] * p[e];
                 const double apn = coef[1] * Aw[e] + coef[2] * Ap[e];
                 const double xn = coef[0] * x[e] + pn;
                 const double axn = coef[0] * Ax[e] + apn;
@@ -1703,19 +1838,33 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 p[e] = pn;
                 Ax[e] = axn;
                 Ap[e] = apn;
-                const double ri = axn - theta * xn;
-                r[e] = ri;
-                rs[0] += fabs(ri);
+                rs[0] += fabs(axn - theta * xn);
+                // the local sweeps follow the same recurrences
+                const double zpn = coef[1] * zget(kZw, e) + coef[2] * zget(kZp, e);
+                const double zapn = coef[1] * zget(kZAw, e) + coef[2] * zget(kZAp, e);
+                zset(kZx, e, coef[0] * zget(kZx, e) + zpn);
+                zset(kZp, e, zpn);
+                zset(kZAx, e, coef[0] * zget(kZAx, e) + zapn);
+                zset(kZAp, e, zapn);
             }
-            double yloc_e, zA_s;
-            local_sweeps(yloc_e, zA_s);
-            const double bs = block_sum_p<1>(rs, sred);
-            if (tid == 0) {
-                const int xn = (par ^ 1) * kPMaxBlocks;
-                st_slot(xb, kSlotY + xn + b, yloc_e, stamp + 1.0);
-                st_slot(xb, kSlotZ + xn + b, zA_s, stamp + 1.0);
-                st_slot(xb, kSlotRp + xn + b, bs, stamp + 1.0);
+            if (wave == 0) {
+                // ... and so do everybody's interface scalars (lane j = workgroup j)
+                if (lane < nb) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {   // q = 0: Y (forward), 1: Z (backward)
+                        const double npv = coef[1] * s_new[q][lane] + coef[2] * s_if[2 + q][lane];
+                        const double napv = coef[1] * s_new[2 + q][lane] + coef[2] * s_if[6 + q][lane];
+                        s_if[0 + q][lane] = coef[0] * s_if[0 + q][lane] + npv;
+                        s_if[2 + q][lane] = npv;
+                        s_if[4 + q][lane] = coef[0] * s_if[4 + q][lane] + napv;
+                        s_if[6 + q][lane] = napv;
+                    }
+                }
+                interface_of_r(theta);
             }
+            PTICK(6);
+            const double bs = block_sum_p<1>(rs, sred);  // its barrier also publishes s_vin / s_vinb
+            if (tid == 0) st_slot(xb, kSlotRp + (par ^ 1) * kPMaxBlocks + b, bs, stamp + 1.0);
         }
         PTICK(7);
     }
@@ -1730,8 +1879,8 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         a.prof[8] += (long long)__builtin_amdgcn_s_memtime() - pstart;
     }
     if (tid == 0 && a.prof) {
-        a.prof[16 + b] += pacc[4];       // per-workgroup gather time
-        a.prof[16 + 64 + b] += pacc[6];  // per-workgroup wait for the Gram sums
+        a.prof[16 + b] += pacc[1];       // per-workgroup gather time
+        a.prof[16 + 64 + b] += pacc[4];  // per-workgroup wait for the Gram sums
     }
     if (b == 0 && tid == 0) {
         sc->theta = theta;
@@ -2662,7 +2811,7 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
     if (mac->prof) {
         long long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(h, mac->prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            static const char* nm[9] = {"pollA", "A", "pollB", "B", "gatherC", "C", "pollD", "D", "total"};
+            static const char* nm[9] = {"w", "gather", "gram", "sweeps", "pollD", "rr", "update", "rsum", "total"};
             fprintf(stderr, "[cslam mac prof] iters %lld; s_memtime ticks/iter:", (long long)mac->spmv_count);
             for (int k = 0; k < 9; ++k)
                 fprintf(stderr, " %s %.1f", nm[k], h[k] / (double)std::max<int64_t>(1, mac->spmv_count));
