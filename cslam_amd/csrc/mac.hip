@@ -1051,6 +1051,36 @@ __device__ inline Aff2 wave_scan_aff2(Aff2 v) {
     return v;
 }
 
+// inclusive scan in DESCENDING lane order (lane i: the elements of lanes 63, 62, .., i composed in
+// that order) without reversing the wave: row_shl steps inside the rows of 16, then the totals of
+// the higher rows (three v_readlane each) are applied in front.  The backward sweep used to
+// reverse its operands through the LDS crossbar (ds_bpermute) and back: 12 crossbar ops per scan.
+constexpr int kDppRowShl = 0x100;        // + n: lane i reads lane i+n of its row of 16
+__device__ inline Aff2 wave_rscan_aff2(Aff2 v) {
+#define CSLAM_SCAN_STEP(N)                                                                       \
+    {                                                                                            \
+        const Aff2 o{dpp_mov<kDppRowShl + N>(v.m, 1.0), dpp_mov<kDppRowShl + N>(v.c1, 0.0),      \
+                     dpp_mov<kDppRowShl + N>(v.c2, 0.0)};                                        \
+        v = compose2(o, v);                                                                      \
+    }
+    CSLAM_SCAN_STEP(1)
+    CSLAM_SCAN_STEP(2)
+    CSLAM_SCAN_STEP(4)
+    CSLAM_SCAN_STEP(8)
+#undef CSLAM_SCAN_STEP
+    const Aff2 t3{lane_bcast(v.m, 48), lane_bcast(v.c1, 48), lane_bcast(v.c2, 48)};
+    const Aff2 t2{lane_bcast(v.m, 32), lane_bcast(v.c1, 32), lane_bcast(v.c2, 32)};
+    const Aff2 t1{lane_bcast(v.m, 16), lane_bcast(v.c1, 16), lane_bcast(v.c2, 16)};
+    const Aff2 p32 = compose2(t3, t2);
+    const Aff2 p321 = compose2(p32, t1);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    Aff2 pre{1.0, 0.0, 0.0};
+    if (row == 2) pre = t3;
+    if (row == 1) pre = p32;
+    if (row == 0) pre = p321;
+    return compose2(pre, v);
+}
+
 constexpr int kPT = 512;
 constexpr int kPWaves = kPT / 64;
 constexpr int kPMaxBlocks = 64;  // one wave folds all workgroup composites
@@ -1161,11 +1191,11 @@ __device__ inline void block_scan_p(Aff t, Aff* swave /* [kPWaves] */, Aff& excl
 template <bool REV>
 __device__ inline void block_scan_p2(Aff2 t, Aff2* swave /* [kPWaves] */, Aff2& excl, Aff2& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    Aff2 v = REV ? Aff2{wave_reverse(t.m), wave_reverse(t.c1), wave_reverse(t.c2)} : t;
-    v = wave_scan_aff2(v);
-    Aff2 ex{dpp_mov<kDppWaveShr1>(v.m, 1.0), dpp_mov<kDppWaveShr1>(v.c1, 0.0),
-            dpp_mov<kDppWaveShr1>(v.c2, 0.0)};
-    if (lane == 63) swave[wave] = v;
+    // REV: sweep order = descending thread id; the scan runs in that direction natively
+    const Aff2 v = REV ? wave_rscan_aff2(t) : wave_scan_aff2(t);
+    constexpr int kNext = REV ? kDppWaveShl1 : kDppWaveShr1;   // the lane one sweep position earlier
+    Aff2 ex{dpp_mov<kNext>(v.m, 1.0), dpp_mov<kNext>(v.c1, 0.0), dpp_mov<kNext>(v.c2, 0.0)};
+    if (lane == (REV ? 0 : 63)) swave[wave] = v;
     __syncthreads();
     Aff2 pre{1.0, 0.0, 0.0};
     total = Aff2{1.0, 0.0, 0.0};
@@ -1176,8 +1206,7 @@ __device__ inline void block_scan_p2(Aff2 t, Aff2* swave /* [kPWaves] */, Aff2& 
         if (REV ? (k > wave) : (k < wave)) pre = compose2(pre, sk);
         total = compose2(total, sk);
     }
-    ex = compose2(pre, ex);
-    excl = REV ? Aff2{wave_reverse(ex.m), wave_reverse(ex.c1), wave_reverse(ex.c2)} : ex;
+    excl = compose2(pre, ex);
 }
 
 // sum over workgroups of one published double per workgroup (lane j of the calling wave polls
@@ -1579,6 +1608,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         return done != 0;
     };
     int k = 0;
+    double rs_pending = 0.0;
     if (!done) converged();  // the bootstrap's residual (a warm start may be there already)
     for (; !done; ++k) {
         const double stamp = stamp0 + 1.0 + (double)k;
@@ -1591,7 +1621,7 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
         const int wslot = kSlotW + par * (int)a.wstride;
         {
             const double yin = s_vin, zin = s_vinb;
-            double ws[1] = {0.0};
+            double ws[2] = {0.0, rs_pending};   // sum of w (its mean is projected out), ||r||_1 part
 #pragma unroll
             for (int e = E - 1; e >= 0; --e) {
                 const double zf = kConstInLds ? s_zf[tid * E + e] : zF[e];
@@ -1601,8 +1631,10 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 ws[0] += v;
                 if (publish[e]) st_slot(xb, wslot + i0 + e, v, stamp);
             }
-            const double bs = block_sum_p<1>(ws, sred);
+            const double bs = block_sum_p<2>(ws, sred);
             if (tid == 0) st_slot(xb, kSlotPs + xo + b, bs, stamp);
+            // the bootstrap published (and everybody folded) the first residual itself
+            if (tid == 1 && k > 0) st_slot(xb, kSlotRp + xo + b, bs, stamp);
         }
         PTICK(0);
 
@@ -1863,8 +1895,8 @@ __global__ __launch_bounds__(kPT) void k_lobpcg_persistent(PArgs a) {
                 interface_of_r(theta);
             }
             PTICK(6);
-            const double bs = block_sum_p<1>(rs, sred);  // its barrier also publishes s_vin / s_vinb
-            if (tid == 0) st_slot(xb, kSlotRp + (par ^ 1) * kPMaxBlocks + b, bs, stamp + 1.0);
+            rs_pending = rs[0];   // summed and published with the next iteration's mean (B)
+            __syncthreads();      // s_vin / s_vinb are wave 0's
         }
         PTICK(7);
     }
