@@ -55,6 +55,34 @@ struct DevBuf {
     }
 };
 
+// Growable pinned host allocation (device-visible under the same address: hipHostMalloc maps it);
+// contents are NOT preserved by reserve().
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want) {
+        if (want <= bytes) return CSLAM_OK;
+        if (p) {
+            CSLAM_HIP_TRY(hipHostFree(p));
+            p = nullptr;
+            bytes = 0;
+        }
+        size_t grown = want + want / 4;
+        CSLAM_HIP_TRY(hipHostMalloc(&p, grown, hipHostMallocDefault));
+        bytes = grown;
+        return CSLAM_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
 int device_cu_count(int device_id, int* cus);
 
 // knn.hip → shard.hip (internal).  pool_append_on: cslam_pool_add_dev without the cross-stream

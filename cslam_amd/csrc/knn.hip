@@ -1498,6 +1498,7 @@ struct cslam_pool {
     hipStream_t stream = nullptr;
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, fault;
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
+    PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
@@ -2147,6 +2148,8 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();
+    p->pin_q.release();
+    p->pin_out.release();
     p->h_rows.release();
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -2331,9 +2334,29 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
     size_t qbytes = (size_t)n_queries * p->dim * sizeof(float);
     size_t obytes = (size_t)n_queries * k;
     CSLAM_TRY(p->h_q.reserve(qbytes));
+    CSLAM_TRY(order_after_dev(p, p->stream));
+    // Small calls (the per-keyframe pattern of the reference): queries through a pinned bounce
+    // buffer (a pageable hipMemcpyAsync stages inside the runtime, ~30 us for 256 KB), results
+    // written by the select kernels STRAIGHT into pinned host memory (device-visible under the
+    // same address) — no device-to-host copies at all, one stream synchronisation.
+    const bool small = qbytes <= ((size_t)8 << 20) && obytes <= ((size_t)1 << 16);
+    if (small) {
+        const size_t sim_off = (obytes * sizeof(int32_t) + 63) / 64 * 64;
+        CSLAM_TRY(p->pin_q.reserve(qbytes));
+        CSLAM_TRY(p->pin_out.reserve(sim_off + obytes * sizeof(float)));
+        memcpy(p->pin_q.p, queries, qbytes);
+        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+        int32_t* idx_pin = p->pin_out.as<int32_t>();
+        float* sim_pin = reinterpret_cast<float*>(static_cast<char*>(p->pin_out.p) + sim_off);
+        CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, idx_pin, sim_pin, p->stream));
+        CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+        memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));
+        memcpy(out_sim, sim_pin, obytes * sizeof(float));
+        p->dev_pending = false;
+        return CSLAM_OK;
+    }
     CSLAM_TRY(p->h_idx.reserve(obytes * sizeof(int32_t)));
     CSLAM_TRY(p->h_sim.reserve(obytes * sizeof(float)));
-    CSLAM_TRY(order_after_dev(p, p->stream));
     CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, queries, qbytes, hipMemcpyHostToDevice, p->stream));
     CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, p->h_idx.as<int32_t>(),
                               p->h_sim.as<float>(), p->stream));
