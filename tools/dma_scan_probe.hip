@@ -188,6 +188,173 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Half stages: the ring slot is 16 rows x 128 floats (8 KiB + pad), FOUR slots per wave in the
+// same LDS.  One DMA instruction moves TWO rows x 512 B (lanes 0-31: the even row of the pair,
+// lanes 32-63: the odd one); the odd row's 16-B segments are XOR-1 swizzled on the SOURCE side
+// (LDS position j holds global segment j ^ 1), so that the 16 lanes of a ds_read_b128 pass — the
+// 16 rows at one k offset — hit 16 different 16-B slots: pair p sits at p * 1056 B (32-B steps
+// mod 256), the odd row 512 B behind the even one and one segment aside.
+// A slot is in the consumer's hands for 8 ds_read_b128 + 32 MFMAs instead of 16 + 64.
+// Work order: (panel, slice kc, strip s, half h); chain order unchanged -> bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalfB = 8 * kPieceB;
+
+struct CursorH {
+    int64_t lo;
+    int rows, ns, p, kc, s, h;
+};
+
+template <int NS, int NW, int NST, int AUX, int MODE = 3>
+__global__ __launch_bounds__(NW * 64) void k_scan_half(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
+                                                       const float* __restrict__ Q, float* __restrict__ dots,
+                                                       int64_t dots_stride, int n_panels, int ppw) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x * NW + wave;
+    char* ring = lds + wave * NST * kHalfB;
+    const int nkc = dp >> 8;
+    const int p_begin = w * ppw;
+    int p_end = p_begin + ppw;
+    if (p_end > n_panels) p_end = n_panels;
+    if (p_begin >= p_end) return;
+
+    auto panel = [&](CursorH& c, int p) {
+        c.p = p;
+        c.lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        c.rows = (int)(hi - c.lo);
+        c.ns = (c.rows + 15) >> 4;
+        c.kc = 0;
+        c.s = 0;
+        c.h = 0;
+    };
+    auto advance = [&](CursorH& c) {
+        if (++c.h < 2) return;
+        c.h = 0;
+        if (++c.s < c.ns) return;
+        c.s = 0;
+        if (++c.kc < nkc) return;
+        panel(c, c.p + 1);
+    };
+    // DMA side: lane -> (row of the pair, swizzled 16-B segment)
+    const int sub = lane >> 5;
+    const int seg = (lane & 31) ^ sub;
+    const int64_t sub_off = (int64_t)sub * xs;
+    auto issue = [&](const CursorH& c, char* slot) {
+        int cnt = c.rows - 16 * c.s;          // valid rows of the strip (>= 1)
+        cnt = cnt > 16 ? 16 : cnt;
+        const int npair = (cnt + 1) >> 1;
+        // even-row address of pair 0 (per lane only through the segment); pair j is 2 j rows on
+        // (scalar), the odd row one row further (per-lane constant sub_off) — except for an odd
+        // tail, where the missing row repeats the even one
+        const float* base = X + (c.lo + 16 * c.s) * xs + c.kc * 256 + c.h * 128 + seg * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < npair) {
+                const float* a = base + (int64_t)(2 * j) * xs;
+                if (2 * j + 1 < cnt) a += sub_off;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                                 (__attribute__((address_space(3))) void*)(slot + j * kPieceB), 16, 0, AUX);
+            }
+        return npair;
+    };
+    // reader side: row r of the strip, k offset g within a 16-float block
+    const int rd_off = (r >> 1) * kPieceB + (r & 1) * 512 + ((g ^ (r & 1)) * 16);
+
+    const float* qrow = Q + (int64_t)r * dp + 4 * g;
+    f32x4 bc[16], bn[16];
+    CursorH ic;
+    panel(ic, p_begin);
+    int y[NST];
+    int yq = 0;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) y[i] = 0;
+    auto bump = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) y[i] += k;
+        yq += k;
+    };
+    load_b16(bn, qrow);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie16(bn);
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (ic.p < p_end) { const int c = issue(ic, ring + i * kHalfB); bump(c); y[i] = 0; advance(ic); }
+
+    int t = 0;
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t lo = (int64_t)p * n / n_panels;
+        const int64_t hi = (int64_t)(p + 1) * n / n_panels;
+        const int ns = (int)((hi - lo + 15) >> 4);
+        f32x4 acc[NS], tot[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { acc[s] = f32x4{0, 0, 0, 0}; tot[s] = f32x4{0, 0, 0, 0}; }
+        for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            {
+                const int kn = kc + 1 < nkc ? kc + 1 : 0;
+                load_b16(bn, qrow + kn * 256);
+                bump(16); yq = 0;
+            }
+            // one half stage: wait, read, hand the slot back, 32 MFMAs on bc[8 h ..]
+            auto half = [&](f32x4& accs, const f32x4* bh) __attribute__((always_inline)) {
+                const int slot = t;
+                char* sp = ring + slot * kHalfB;
+                int yc = y[0];
+#pragma unroll
+                for (int i = 1; i < NST; ++i) yc = slot == i ? y[i] : yc;
+                wait_vm_dyn(yc);
+                f32x4 a[8];
+                const char* ap = sp + rd_off;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = (MODE & 4) ? f32x4{1, 2, 3, 4} : *reinterpret_cast<const f32x4*>(ap + i * 64);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (ic.p < p_end) {
+                    const int c = issue(ic, sp);
+                    advance(ic);
+                    bump(c);
+#pragma unroll
+                    for (int i = 0; i < NST; ++i) y[i] = slot == i ? 0 : y[i];
+                }
+                if (MODE & 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            accs = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bh[i][j], accs, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) accs += a[i] * bh[i];
+                }
+                t = t + 1 == NST ? 0 : t + 1;
+            };
+#pragma clang loop unroll(full)
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    half(acc[s], &bc[0]);
+                    half(acc[s], &bc[8]);
+                    if ((kc & 1) || kc + 1 == nkc) { tot[s] = tot[s] + acc[s]; acc[s] = f32x4{0, 0, 0, 0}; }
+                }
+            }
+            wait_vm_dyn(yq); tie16(bn);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < ns) {
+                const int64_t r0 = lo + 16 * s + 4 * g;
+                float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < hi) out[e] = tot[s][e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Piece-granular ring: the wave's LDS ring is RP one-row pieces (not whole stages); a stage's 16
 // slots are refilled with the next pieces in line as soon as it has been read, so RP-16 .. RP
 // KiB stay in flight per wave (stage ring of 2: 16 .. 32).
@@ -416,6 +583,42 @@ void run(const char* name, const float* X, int64_t n, int dp, const float* Q, fl
     fflush(stdout);
 }
 
+template <int NS, int NW, int NST, int AUX, int MODE = 3>
+void run_half(const char* name, const float* X, int64_t n, int dp, const float* Q, float* dots, const float* ref, int64_t ds,
+              int cus, bool check) {
+    const int n_waves = cus * NW;
+    int ppw = (int)((n + (int64_t)n_waves * 16 * NS - 1) / ((int64_t)n_waves * 16 * NS));
+    if (ppw < 1) ppw = 1;
+    int n_panels = n_waves * ppw;
+    if ((int64_t)n_panels > n) { n_panels = (int)n; }
+    const size_t ldsb = (size_t)NW * NST * kHalfB;
+    CK(hipFuncSetAttribute((const void*)k_scan_half<NS, NW, NST, AUX, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    CK(hipMemset(dots, 0xFF, (size_t)16 * ds * 4));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9, sum = 0; int reps = check ? 3 : 12;
+    const int blocks = (n_panels + ppw * NW - 1) / (ppw * NW);
+    for (int rep = 0; rep < reps; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_scan_half<NS, NW, NST, AUX, MODE>), dim3(blocks), dim3(NW * 64), ldsb, 0, X, (int64_t)dp, n, dp, Q, dots, ds, n_panels, ppw);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2 || reps < 4) { sum += ms; if (ms < best) best = ms; }
+    }
+    CK(hipGetLastError());
+    double bytes = (double)n * dp * 4;
+    long bad = -1;
+    if (check) {
+        std::vector<float> a((size_t)16 * ds), b((size_t)16 * ds);
+        CK(hipMemcpy(a.data(), dots, a.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), ref, b.size() * 4, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (int q = 0; q < 16; ++q) for (int64_t i = 0; i < n; ++i) if (memcmp(&a[q * ds + i], &b[q * ds + i], 4)) { if (bad < 5) printf("   mismatch q%d row%lld: %g vs %g\n", q, (long long)i, a[q * ds + i], b[q * ds + i]); ++bad; }
+    }
+    printf("%-34s HALF NST=%d AUX=%d NS=%d NW=%d blocks=%d ppw=%d  best %.4f ms avg %.4f ms  %.0f GB/s (best) mismatches=%ld\n", name, NST, AUX, NS, NW, blocks, ppw, best,
+           sum / (reps < 4 ? reps : reps - 2), bytes / best / 1e6, bad);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     int64_t n = argc > 1 ? atoll(argv[1]) : 100000;
     int dp = argc > 2 ? atoi(argv[2]) : 4096;
@@ -431,6 +634,19 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_ref, dim3((unsigned)((n + 255) / 256), 16), dim3(256), 0, 0, X, (int64_t)dp, n, dp, Q, ref, ds);
     CK(hipDeviceSynchronize());
     printf("n=%lld dp=%d cus=%d\n", (long long)n, dp, cus);
+    if (argc > 3 && atoi(argv[3]) == 1) {
+        // half-stage ring vs the shipped whole-stage ring, alternating, bit-exact check first
+        run_half<8, 4, 4, 2>("half stages 4w x 4 nt (check)", X, n, dp, Q, dots, ref, ds, cus, true);
+        for (int round = 0; round < 2; ++round) {
+            run<8, 4, 3, 2, 2>("whole stages 4w x 2 nt", X, n, dp, Q, dots, ref, ds, cus, false);
+            run_half<8, 4, 4, 2>("half stages 4w x 4 nt", X, n, dp, Q, dots, ref, ds, cus, false);
+            run_half<8, 4, 4, 2, 1>("half: VALU instead of MFMA", X, n, dp, Q, dots, ref, ds, cus, false);
+            run_half<8, 4, 4, 2, 5>("half: VALU, no LDS reads", X, n, dp, Q, dots, ref, ds, cus, false);
+            run_half<8, 4, 4, 2, 7>("half: MFMA, no LDS reads", X, n, dp, Q, dots, ref, ds, cus, false);
+            run_half<8, 4, 2, 2>("half stages 4w x 2 slots nt", X, n, dp, Q, dots, ref, ds, cus, false);
+        }
+        return 0;
+    }
     // cost decomposition of the shipped structure (NS = 8, 4 waves x 2 stages, nt); MODE bits:
     // 1 = B loads (queries from L2), 2 = MFMA (else 64 VALU fma), 4 = NO LDS reads of the stage
     for (int round = 0; round < 2; ++round) {
