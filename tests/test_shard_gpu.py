@@ -257,3 +257,66 @@ def test_device_shard_split_best_mode(gpu, world, maxb):
         assert results[r] == results[0]
         assert records[r].tobytes() == records[0].tobytes()
         assert local[r] == []
+
+
+def test_loopback_communicator_step_matches_oracle(gpu):
+    """cslam_comm_init_loopback (every all-gather copies the caller's block into all slots, one
+    kernel) under the split best-match step: robot 1 of 4 sees its own descriptors as everybody's.
+    Each fetched record stream is rebuilt on the host from the oracle: per foreign slot the best
+    OLD row (lcsm.py:69-75) and, when it beats every older row, the best row of the block just
+    appended (lcsm.py:47-55).  Pipelined publishes (two steps ahead) exercise the explicit row
+    windows: rows of later blocks are already in the pool when a step is matched."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd.multi_robot import DeviceShard, LoopbackComm
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    R, me, bmax, dim, thr, steps = 4, 1, 4, 256, 0.8, 9
+    rs = np.random.RandomState(3)
+    places = rs.rand(12, dim).astype(np.float32)
+    pool = NearestNeighborsMatching(dim=dim)
+    cd, cr = LoopbackComm(me, R, 0), LoopbackComm(me, R, 0)
+    sh = DeviceShard(pool, me, R, bmax, thr, cd, cr, nb_best_matches=0)
+    blocks, kf = [], 0
+    for t in range(steps):
+        b = int(rs.randint(1, bmax + 1))
+        x = (places[rs.randint(0, len(places), size=b)] + 0.04 * rs.rand(b, dim)).astype(np.float32)
+        blocks.append((x, list(range(kf, kf + b))))
+        kf += b
+    dev = [torch.from_numpy(x).cuda() for x, _ in blocks]
+    got = []
+    sh.publish(dev[0], blocks[0][1])
+    for t in range(steps):
+        if t + 1 < steps:
+            sh.publish(dev[t + 1], blocks[t + 1][1])        # one step ahead of the match
+        sh.match()
+        got.append(sh.fetch_records())
+    # host replay
+    rows = np.zeros((0, dim), np.float32)
+    kfs = []
+    for t, (x, ids) in enumerate(blocks):
+        n0 = rows.shape[0]
+        rows = np.vstack([rows, x])
+        kfs = kfs + ids
+        exp = []
+        for s in range(R):                                   # every rank's records are the same
+            for slot_rank in range(R):                       # gathered descriptors, rank order
+                if slot_rank == me:
+                    continue
+                for j, kf_s in enumerate(ids):
+                    ia, sa = -1, 0.0
+                    if n0:
+                        i, v, _ = oracle_knn.search(rows[:n0], x[j:j + 1], 1)
+                        ia, sa = int(i[0, 0]), np.float32(v[0, 0])
+                    i, v, _ = oracle_knn.search(rows[n0:], x[j:j + 1], 1)
+                    ic, sc = int(i[0, 0]) + n0, np.float32(v[0, 0])
+                    if ia >= 0 and float(sa) >= thr:
+                        exp.append((me, kfs[ia], slot_rank, kf_s, sa))
+                    if float(sc) >= thr and not (ia >= 0 and sa >= sc):
+                        exp.append((slot_rank, kf_s, me, kfs[ic], sc))
+        rec = got[t]
+        assert len(rec) == len(exp), (t, len(rec), len(exp))
+        for r, e in zip(rec, exp):
+            assert (int(r[0]), int(r[1]), int(r[2]), int(r[3])) == e[:4]
+            assert np.float32(r[4]) == e[4]
+    assert sum(len(g) for g in got) > 20
+    assert pool.n == kf
+    sh.close(); cd.close(); cr.close(); pool.close()
