@@ -391,9 +391,10 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D, X):
     # MAC first: the solver is latency-bound, and the clocks sag for a while after the
     # 100-TFLOP/s bulk pass below
     try:
-        from mac_bench_util import acm_select_bench, fiedler_bench
+        from mac_bench_util import acm_select_bench, cfg1_bench, fiedler_bench
         out.update(fiedler_bench())
         out.update(acm_select_bench())
+        out.update(cfg1_bench())     # BASELINE configs[0]: the reference's own CPU-runnable case
     except ImportError:
         pass
     q1 = torch.rand((1, D), device=dev, generator=g)

@@ -1504,6 +1504,8 @@ struct cslam_pool {
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, fault;
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
+    PinBuf pin_rows;                   // pinned ring of cslam_pool_add's small appends
+    size_t pin_rows_used = 0;
     // profiling of the scan kernel
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
@@ -2155,6 +2157,7 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->h_sim.release();
     p->pin_q.release();
     p->pin_out.release();
+    p->pin_rows.release();
     p->h_rows.release();
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -2167,6 +2170,29 @@ int cslam_pool_add(cslam_pool_t* p, const float* rows, int64_t n_rows) {
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     CSLAM_TRY(order_after_dev(p, p->stream));
     CSLAM_TRY(pool_grow(p, p->n + n_rows, p->stream));
+    // Small appends (add_item: one row per keyframe): the rows go into a pinned ring that the
+    // append kernel reads in place (device-visible host memory) — no copy call, no
+    // synchronisation; the ring is drained when it wraps.  Later calls on this handle's stream are
+    // ordered behind the kernel, calls on other streams through the handle's event.
+    const size_t small_bytes = (size_t)n_rows * p->dim * sizeof(float);
+    constexpr size_t kPinRing = (size_t)1 << 20;
+    if (small_bytes <= kPinRing / 8) {
+        CSLAM_TRY(p->pin_rows.reserve(kPinRing));
+        const size_t need = (small_bytes + 255) / 256 * 256;
+        if (p->pin_rows_used + need > kPinRing) {
+            CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));   // every earlier append has read its slot
+            p->pin_rows_used = 0;
+        }
+        float* slot = reinterpret_cast<float*>(static_cast<char*>(p->pin_rows.p) + p->pin_rows_used);
+        memcpy(slot, rows, small_bytes);
+        p->pin_rows_used += need;
+        hipLaunchKernelGGL(k_append_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, p->stream, slot,
+                           (int64_t)p->dim, p->dim, p->rows, p->xs, p->dp, p->n, n_rows, p->inv_norm,
+                           (p->dim & 3) == 0 ? 1 : 0);
+        CSLAM_HIP_TRY(hipGetLastError());
+        p->n += n_rows;
+        return mark_dev(p, p->stream);
+    }
     // dense host rows → device staging with plain 1-D copies (a strided 2-D copy out of pageable
     // memory cost ~200 us for ONE 16 KB row), then the device-side pad-and-append of add_dev;
     // staged in chunks of at most 64 MB

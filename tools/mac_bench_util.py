@@ -98,3 +98,48 @@ def acm_select_bench(poses_per_robot=25_000, nb_candidates=200_000, budget=500, 
         dt = time.perf_counter() - t0
     return {"acm_select_candidates_ms": dt * 1e3, "acm_candidates": n_cand, "acm_selected": len(selected),
             "acm_solver_exceptions": acm.last_solver_exceptions}
+
+
+def cfg1_bench():
+    """BASELINE.json configs[0] on the HIP path through the reference-shaped host API, one keyframe
+    at a time: 2 robots x 1000 keyframes x 128-d, interleaved add_local / add_other (2000
+    best-match searches, threshold 0.0), one fixed inter-robot edge, select_candidates(100).
+    The reference's own run of this scenario on 8 CPU cores: 1.46 s + 1.10 s."""
+    from collections import namedtuple
+    from cslam_amd.algebraic_connectivity_maximization import EdgeInterRobot
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    Msg = namedtuple("GlobalDescriptor", ["keyframe_id", "robot_id", "descriptor"])
+
+    class Node:
+        def get_logger(self):
+            class L:
+                def info(self, *a, **k):
+                    pass
+                debug = error = info
+            return L()
+
+    params = {"robot_id": 0, "max_nb_robots": 2, "frontend.sensor_type": "stereo",
+              "frontend.similarity_threshold": 0.0, "frontend.nb_best_matches": 10,
+              "frontend.intra_loop_min_inbetween_keyframes": 10}
+    desc = np.random.RandomState(0).rand(2, 1000, 128).astype(np.float32)
+    desc = desc / np.linalg.norm(desc, axis=2, keepdims=True)
+    other = [desc[1, kf].tolist() for kf in range(1000)]      # the message payload is a list
+    out = {}
+    for rep in range(2):                                       # first pass warms the library up
+        l = LoopClosureSparseMatching(params, Node())
+        t0 = time.perf_counter()
+        n_matches = 0
+        for kf in range(1000):
+            n_matches += len(l.add_local_global_descriptor(desc[0, kf], kf))
+            n_matches += l.add_other_robot_global_descriptor(Msg(kf, 1, other[kf])) is not None
+        t_match = time.perf_counter() - t0
+        l.candidate_selector.add_fixed_edge(EdgeInterRobot(0, 999, 1, 999, 1.0))
+        with redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            sel = l.select_candidates(100, {0: True, 1: True})
+            t_sel = time.perf_counter() - t0
+        out = {"cfg1_match_phase_s": t_match, "cfg1_searches": 2000, "cfg1_candidates": n_matches,
+               "cfg1_candidates_per_s": n_matches / t_match, "cfg1_select_candidates_ms": t_sel * 1e3,
+               "cfg1_selected": len(sel),
+               "cfg1_reference_cpu_8cores": "match phase 1.46 s, select_candidates(100) 1.10 s (BASELINE.md)"}
+    return out
