@@ -393,7 +393,6 @@ class DeviceShard(object):
         self.handle = h
         self._cap = int(self._L.cslam_shard_max_records(h))
         self._buf = np.empty(self._cap, dtype=RECORD_DTYPE)
-        self._pending_items = []   # keyframe ids of published blocks, in order
         if pool.n:
             kfs = np.asarray([pool.items[i] for i in range(pool.n)], dtype=np.int32)
             _lib.check(self._L.cslam_shard_set_keyframes(h, 0, _lib.ptr(kfs), len(kfs)))
@@ -418,13 +417,12 @@ class DeviceShard(object):
         self._lib.check(self._L.cslam_shard_publish(self.handle, ctypes.c_void_p(ptr), int(stride),
                                                     self._lib.ptr(kfs) if b else None, int(b),
                                                     ctypes.c_void_p(stream or 0)))
-        self._pending_items.append([int(k) for k in keyframe_ids])
+        for kf in keyframe_ids:                     # the library appended the own block (publish time)
+            self.pool.items[self.pool.n] = int(kf)
+            self.pool.n += 1
 
     def match(self, stream=None):
         self._lib.check(self._L.cslam_shard_match(self.handle, ctypes.c_void_p(stream or 0)))
-        for kf in self._pending_items.pop(0):       # the library appended the own block
-            self.pool.items[self.pool.n] = kf
-            self.pool.n += 1
 
     def fetch_records(self):
         """All ranks' records of the oldest matched step as a structured array (rank order, then
