@@ -949,6 +949,105 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_scan_dma_ks: the scan for SMALL pools (fewer 16-row strips than CUs) and long descriptors.
+//   k_scan_dma gives a strip to one wave, which then walks all dp/256 slices one after the other
+//   with two stages in flight: at 4096-d that is 16 dependent HBM round trips for a kilobyte-sized
+//   pool (47 us for 1000 rows) while most of the chip idles.  Here a BLOCK owns the strip and its
+//   four waves split the K range: the 512-float chunks are independent fmaf chains,
+//   so wave v multiplies chunks [v c, (v+1) c) — same LDS-DMA pieces, ring and MFMA order as
+//   k_scan_dma — and leaves each chunk's partial in the LDS; after ONE barrier wave 0 folds them
+//   in chunk order (tot = ((0 + c0) + c1) + ...), exactly the sequential fold → identical bits.
+//   Queries are read from the staged block ([16][dp], zero padded rows); raw dots out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kKsMaxChunks = 16;   // dp <= 8192
+
+template <int AUX>
+__global__ __launch_bounds__(256) void k_scan_dma_ks(const float* __restrict__ X, int64_t xs, int64_t n,
+                                                     int dp, const float* __restrict__ Qstage,
+                                                     int m_valid, float* __restrict__ dots,
+                                                     int64_t dots_stride) {
+    extern __shared__ __attribute__((aligned(16))) char ks_lds[];
+    constexpr int NW = 4, NST = 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    char* ring = ks_lds + wave * NST * kDmaStageB;
+    f32x4* part = reinterpret_cast<f32x4*>(ks_lds + NW * NST * kDmaStageB);   // [chunk][lane]
+    const int nkc = dp >> 8;
+    const int nchunks = (nkc + 1) >> 1;
+    const int cpw = (nchunks + NW - 1) / NW;          // chunks per wave
+    const int kc0 = 2 * cpw * wave;
+    const int kc1 = min(nkc, kc0 + 2 * cpw);
+    const int64_t row_lo = (int64_t)blockIdx.x * 16;
+    int cnt = (int)(n - row_lo);                      // valid rows of the strip (>= 1)
+    cnt = cnt > 16 ? 16 : cnt;
+
+    if (kc0 < kc1) {
+        auto issue = [&](int kc, char* slot) {
+            const float* src = X + row_lo * xs + kc * 256 + lane * 4;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr)
+                if (rr < cnt)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(src + rr * xs),
+                        (__attribute__((address_space(3))) void*)(slot + rr * kDmaPieceB), 16, 0, AUX);
+        };
+        const float* qrow = Qstage + (int64_t)r * dp + 4 * g;
+        f32x4 bc[16], bn[16];
+        load_b16(bn, qrow + kc0 * 256);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tie16(bn);
+        issue(kc0, ring);
+        if (kc0 + 1 < kc1) issue(kc0 + 1, ring + kDmaStageB);
+        f32x4 acc{0.f, 0.f, 0.f, 0.f};
+        int slot = 0;
+        for (int kc = kc0; kc < kc1; ++kc) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            // ALWAYS issued (the last one re-reads the wave's first slice and is never used): an
+            // asm load inside a conditional leaves the compiler free to copy its not-yet-written
+            // output registers at the join
+            load_b16(bn, qrow + (kc + 1 < kc1 ? kc + 1 : kc0) * 256);
+            // younger than stage kc: stage kc+1 (if any) and the B loads just issued
+            wait_vm_dyn((kc + 1 < kc1 ? cnt : 0) + 16);
+            char* sp = ring + slot * kDmaStageB;
+            f32x4 a[16];
+            const char* ap = sp + r * kDmaPieceB + g * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const bool refill = kc + 2 < kc1;
+            if (refill) issue(kc + 2, sp);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bc[i][j], acc, 0, 0, 0);
+            if ((kc & 1) || kc + 1 == nkc) {   // end of a 512-float chunk / of the row
+                part[(kc >> 1) * 64 + lane] = acc;
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            wait_vm_dyn(refill ? cnt : 0);   // the B loads have landed (only the refill is younger)
+            tie16(bn);
+            slot ^= 1;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 tot{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunks; ++c) tot = tot + part[c * 64 + lane];
+        if (r < m_valid) {
+            const int64_t r0 = row_lo + 4 * g;
+            float* out = dots + (int64_t)r * dots_stride + r0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (r0 + e < n) out[e] = tot[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_gemm32: raw dots for MANY queries (the MFMA-bound regime: from ~128 queries per call, see
 // the cost model in compute_dots).
 //   LDS-tiled fp32 GEMM on v_mfma_f32_32x32x2_f32: block = 4 waves (2 x 2), block tile
@@ -1610,6 +1709,17 @@ bool dma_scan_applies(const cslam_pool* p) {
     return p->vn >= kDmaMinRows;
 }
 
+// small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
+// of a block) instead of one wave walking every slice of its strip.  CSLAM_SCAN_KSPLIT=0 keeps
+// k_scan_dma.
+bool ks_scan_applies(const cslam_pool* p, int m) {
+    static const bool ks_env = !(getenv("CSLAM_SCAN_KSPLIT") && atoi(getenv("CSLAM_SCAN_KSPLIT")) == 0);
+    if (!ks_env || m > 16 || !dma_scan_applies(p)) return false;
+    const int64_t strips = (p->vn + 15) / 16;
+    const int nchunks = (p->dp / 256 + 1) / 2;
+    return strips <= p->cus && nchunks >= 4 && nchunks <= kKsMaxChunks;
+}
+
 // k_scan_dma over the row window [v0, v0+vn): either raw dots (best = false) or one (similarity,
 // row) composite per query and panel (best = true, *n_panels_out candidates per query)
 int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
@@ -1696,7 +1806,26 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         const bool use_pc = kern_env && strcmp(kern_env, "pc") == 0;
         // X through LDS-DMA (k_scan_dma, 6.0-6.3 TB/s) for pools that are worth it
         const bool use_dma = dma_scan_applies(p);
-        if (use_dma) {
+        // small pool, long descriptors, staged queries: the block-per-strip K-split kernel
+        const int64_t strips = (p->vn + 15) / 16;
+        const int nchunks = (p->dp / 256 + 1) / 2;
+        if (rnq_out == nullptr && ks_scan_applies(p, m)) {
+            const size_t lds = (size_t)4 * 2 * kDmaStageB + (size_t)nchunks * 64 * sizeof(f32x4);
+            const bool nt = false;   // a pool this small lives in the Infinity Cache between searches
+            (void)nt;
+            static bool attr_set[64] = {};
+            if (!attr_set[p->device & 63]) {
+                CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma_ks<0>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)4 * 2 * kDmaStageB +
+                                                        (size_t)kKsMaxChunks * 64 * sizeof(f32x4))));
+                attr_set[p->device & 63] = true;
+            }
+            hipLaunchKernelGGL((k_scan_dma_ks<0>), dim3((unsigned)strips), dim3(256), lds, st,
+                               p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
+                               dots_stride);
+            p->last_scan_kernel = "k_scan_dma_ks (K split over the block's waves)";
+        } else if (use_dma) {
             int64_t n_panels = 0;
             // rnq_out set: Qstage are the caller's queries read in place (no staging ran)
             CSLAM_TRY(launch_scan_dma(p, Qstage, rnq_out ? q_stride : p->dp, rnq_out ? m : 16, m, dots,
@@ -1900,7 +2029,7 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         const int vec_ok = ((reinterpret_cast<uintptr_t>(qsrc) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         p->q_copies = mb <= 16 ? qrep_max : 1;
         p->q_copy_stride = copy_stride;
-        if (mb <= 16 && vec_ok && p->dim == p->dp && dma_scan_applies(p)) {
+        if (mb <= 16 && vec_ok && p->dim == p->dp && dma_scan_applies(p) && !ks_scan_applies(p, mb)) {
             // the LDS-DMA scan reads the queries where they are and leaves 1/||q|| for the select
             CSLAM_TRY(launch_scan(p, qsrc, mb, dots + (int64_t)q0 * dots_stride, dots_stride, st,
                                   q_stride, p->rnq.as<float>() + q0));
@@ -2069,7 +2198,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
-    if (k == 1 && m <= 16 && dma_scan_applies(p))
+    if (k == 1 && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m))
         return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
     int64_t sims_stride = (p->vn + 63) / 64 * 64;
     const int64_t qc = query_chunk(sims_stride);

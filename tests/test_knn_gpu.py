@@ -460,3 +460,32 @@ def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     np.testing.assert_array_equal(rows, o_idx)
     assert sims.tobytes() == o_sim.tobytes()
     pool.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (1000, 4096, 16, 1),       # the benchmark's descriptor size on a young robot's pool
+    (1000, 4096, 1, 10),
+    (17, 2048, 5, 3),          # two strips, the second with one row; 4 chunks = one per wave
+    (4096, 2048, 16, 1),       # exactly as many strips as CUs
+    (333, 8192, 7, 400),       # 16 chunks, k > n
+    (50, 3072, 16, 1),         # 6 chunks: two waves with two, one with... none for the last
+    (640, 2304, 3, 5),         # odd number of slices (9): the last chunk is half a chunk
+])
+def test_small_pool_k_split_scan_is_bit_identical(gpu, n, d, m, k):
+    """k_scan_dma_ks (pools with fewer strips than CUs, descriptors of >= 4 chunks): the waves of
+    a block split the K range at chunk granularity and wave 0 folds the chunk partials in order —
+    bit-identical to the oracle's sequential fold."""
+    rs = np.random.RandomState(n + d + m + k)
+    X = (rs.rand(n, d).astype(np.float32) - 0.3)
+    Q = rs.rand(m, d).astype(np.float32) - 0.3
+    X[n // 2] = X[0]                                    # a tie → lowest row
+    Q[0] = X[0]
+    pool = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = pool.search_batch(Q, k)
+    assert gpu.cslam_pool_scan_kernel(pool.handle).decode().startswith("k_scan_dma_ks")
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, k)
+    kk = min(k, n)
+    np.testing.assert_array_equal(rows, o_idx[:, :kk])
+    assert sims.tobytes() == o_sim[:, :kk].tobytes()
+    assert rows[0, 0] == 0
+    pool.close()
