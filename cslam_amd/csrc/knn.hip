@@ -1235,12 +1235,15 @@ constexpr int kGdCols = 128, kGdK = 32;
 //   <1, 2>:  64 x 128 tile for the LAST, partial wave of tiles: the rows that do not fill a whole
 //           number of tile waves are cut into half-height tiles so that they spread over the
 //           chip (12.2 waves of tiles cost 12.5 instead of 13)
-template <int TM, int SLOTS>
+//   TJ = 32-column MFMA tiles per wave along the queries (block columns = 64 * TJ): <2, 2, 1> is the
+//   128 x 64 tile for 33..64 queries (and a trailing 64-query block), 2 x 24 KiB per block.
+template <int TM, int SLOTS, int TJ = 2>
 __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
     const float* __restrict__ X, int64_t xs, int64_t n, int dp, const float* __restrict__ Q,
     int m_valid, float* __restrict__ dots, int64_t dots_stride, int n_rowblk, int n_colblk) {
     constexpr int kRows = 64 * TM;                    // X rows per block
-    constexpr int kTileRows = kRows + kGdCols;        // rows of 128 B per stage
+    constexpr int kCols = 64 * TJ;                    // queries per block
+    constexpr int kTileRows = kRows + kCols;          // rows of 128 B per stage
     constexpr int kStageB = kTileRows * kGdK * 4;
     constexpr int kPW = kTileRows / 32;               // DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) char gd_lds[];
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
             if (row >= n) row = n - 1;  // clamp: results of clamped rows are not stored
             src[i] = X + row * xs;
         } else {
-            src[i] = Q + (int64_t)(colblk * kGdCols + trow - kRows) * dp;
+            src[i] = Q + (int64_t)(colblk * kCols + trow - kRows) * dp;
         }
     }
     // quarter `part` of this wave's kPW pieces for `stage`
@@ -1295,22 +1298,22 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
 
     // ---- MFMA side ---------------------------------------------------------------------------
     const int swz = (r32 >> 1) & 7;
-    int a_row[TM], b_row[2];
+    int a_row[TM], b_row[TJ];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a_row[i] = (wr * 32 * TM + i * 32 + r32) * 128;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b_row[j] = (kRows + wc * 64 + j * 32 + r32) * 128;
+    for (int j = 0; j < TJ; ++j) b_row[j] = (kRows + wc * 32 * TJ + j * 32 + r32) * 128;
     int seg_rd[2][2];  // [k-block in stage][v0 / v1] byte offset of the un-swizzled segment
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int half = 0; half < 2; ++half) seg_rd[kb][half] = ((kb * 4 + h + 2 * half) ^ swz) * 16;
 
-    f32x16 acc[TM][2], tot[TM][2];
+    f32x16 acc[TM][TJ], tot[TM][TJ];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 acc[i][j][e] = 0.f;
@@ -1321,14 +1324,14 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
     // pre_stage >= 0 the wave's DMA pieces of that stage are issued a few at a time in the
     // shadow of the MFMAs (issued in one burst before them they kept the matrix pipe idle).
     auto kblock = [&](const char* base, int kb, int pre_stage, int pre_slot) {
-        f32x4 a0[TM], a1[TM], b0[2], b1[2];
+        f32x4 a0[TM], a1[TM], b0[TJ], b1[TJ];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             a0[i] = *reinterpret_cast<const f32x4*>(base + a_row[i] + seg_rd[kb][0]);
             a1[i] = *reinterpret_cast<const f32x4*>(base + a_row[i] + seg_rd[kb][1]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
             b0[j] = *reinterpret_cast<const f32x4*>(base + b_row[j] + seg_rd[kb][0]);
             b1[j] = *reinterpret_cast<const f32x4*>(base + b_row[j] + seg_rd[kb][1]);
         }
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j4], b0[j][j4], acc[i][j],
                                                                      0, 0, 0);
             if (pre_stage >= 0) {
@@ -1348,7 +1351,7 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j4], b1[j][j4], acc[i][j],
                                                                      0, 0, 0);
         }
@@ -1357,7 +1360,7 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 tot[i][j] = tot[i][j] + acc[i][j];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -1401,8 +1404,8 @@ __global__ __launch_bounds__(256, TM <= 2 ? 2 : 1) void k_gemm_dma(
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = colblk * kGdCols + wc * 64 + j * 32 + r32;
+        for (int j = 0; j < TJ; ++j) {
+            const int q = colblk * kCols + wc * 32 * TJ + j * 32 + r32;
             if (q < m_valid) {
                 float* out = dots + (int64_t)q * dots_stride;
                 const int64_t rb = (int64_t)rowblk * kRows + wr * 32 * TM + i * 32 + 4 * h;
@@ -1944,10 +1947,18 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         const int rem = mm % 64;
         return 1.85 * (mm / 64) + (rem == 0 ? 0.0 : rem <= 16 ? 1.0 : rem <= 32 ? 1.12 : 1.85);
     };
-    const bool use_gemm = gemm_env && m >= 96 && p->vn > 0 && 3.2 * ((m + 127) / 128) < scan_cost(m);
+    // 64-column tiles (k_gemm_dma<2,2,1>) where padding to 128 would waste half a tile.  Measured at
+    // 100k x 4096 (tools/m_sweep2.py): a 128 x 64 tile pass runs at 91 TFLOP/s (half the reuse of the
+    // query tile per barrier) = 1.61 units per 64 queries — no better than the 64-query scan pass
+    // (1.85) for 33..64 queries, 13 % better for 129..192 (1.51 vs 1.74 ms at 192)
+    static const int gemm64_env = getenv("CSLAM_GEMM64") ? atoi(getenv("CSLAM_GEMM64")) : 1;
+    const bool narrow = gemm64_env && gemm_env != 32 && gemm_env != 4 && m > 128 && m <= 192;
+    const double gemm_cost = narrow ? 1.61 * ((m + 63) / 64) : 3.2 * ((m + 127) / 128);
+    const bool use_gemm = gemm_env && m >= 96 && p->vn > 0 && gemm_cost < scan_cost(m);
     if (use_gemm) {
-        // MFMA-bound regime: stage the whole chunk once (padded to 128-query tiles), one GEMM
-        const int mq_pad = (m + 127) / 128 * 128;
+        // MFMA-bound regime: stage the whole chunk once (padded to whole query tiles), one GEMM
+        const int gd_cols = narrow ? 64 : kGdCols;
+        const int mq_pad = (m + gd_cols - 1) / gd_cols * gd_cols;
         CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
         const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim,
@@ -1963,30 +1974,32 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         if (use_dma_gemm) {
             // default: 128 x 128 tiles, two blocks per CU; CSLAM_GEMM=4: 256 x 128, one per CU
             const int tm = gemm_env == 4 ? 4 : 2;
-            const int n_colblk = mq_pad / kGdCols;
+            const int n_colblk = mq_pad / gd_cols;
             auto launch = [&](int tmv, int64_t row0, int64_t nrows) -> int {
                 const int rows = 64 * tmv;
                 const int n_rowblk = (int)((nrows + rows - 1) / rows);
                 const int64_t nblocks = (int64_t)((n_rowblk + 7) / 8) * 8 * n_colblk;
-                const size_t lds = (size_t)(tmv == 4 ? 3 : 2) * (rows + kGdCols) * kGdK * 4;
+                const size_t lds = (size_t)(tmv == 4 ? 3 : 2) * (rows + gd_cols) * kGdK * 4;
                 const float* xr = p->rows + (p->v0 + row0) * p->xs;
                 float* dr = dots + row0;
-#define CSLAM_GD_LAUNCH(TMV, SL)                                                                   \
+#define CSLAM_GD_LAUNCH(TMV, SL, TJV)                                                              \
     do {                                                                                           \
         static bool attr_set[64] = {};                                                             \
         if (!attr_set[p->device & 63]) {                                                           \
-            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<TMV, SL>,                    \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_gemm_dma<TMV, SL, TJV>,               \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                               (int)lds));                                          \
             attr_set[p->device & 63] = true;                                                       \
         }                                                                                          \
-        hipLaunchKernelGGL((k_gemm_dma<TMV, SL>), dim3((unsigned)nblocks), dim3(256), lds, st, xr, \
-                           p->xs, nrows, p->dp, p->qstage.as<float>(), m, dr, dots_stride,         \
+        hipLaunchKernelGGL((k_gemm_dma<TMV, SL, TJV>), dim3((unsigned)nblocks), dim3(256), lds, st, \
+                           xr, p->xs, nrows, p->dp, p->qstage.as<float>(), m, dr, dots_stride,     \
                            n_rowblk, n_colblk);                                                    \
     } while (0)
-                if (tmv == 4) CSLAM_GD_LAUNCH(4, 3);
-                else if (tmv == 2) CSLAM_GD_LAUNCH(2, 2);
-                else CSLAM_GD_LAUNCH(1, 2);
+                if (tmv == 4) CSLAM_GD_LAUNCH(4, 3, 2);
+                else if (tmv == 2 && narrow) CSLAM_GD_LAUNCH(2, 2, 1);
+                else if (tmv == 2) CSLAM_GD_LAUNCH(2, 2, 2);
+                else if (narrow) CSLAM_GD_LAUNCH(1, 2, 1);
+                else CSLAM_GD_LAUNCH(1, 2, 2);
 #undef CSLAM_GD_LAUNCH
                 return CSLAM_OK;
             };
@@ -2001,7 +2014,8 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
                 if (full_waves >= 1 && rb < n_rowblk) rb_main = rb;
             }
             const int64_t rows_main = std::min<int64_t>(p->vn, rb_main * rows);
-            p->last_scan_kernel = tm == 4 ? "k_gemm_dma<TM=4,SLOTS=3>" : "k_gemm_dma<TM=2,SLOTS=2>";
+            p->last_scan_kernel = tm == 4 ? "k_gemm_dma<TM=4,SLOTS=3>"
+                                          : (narrow ? "k_gemm_dma<TM=2,SLOTS=2,TJ=1>" : "k_gemm_dma<TM=2,SLOTS=2>");
             CSLAM_TRY(launch(tm, 0, rows_main));
             if (rows_main < p->vn) CSLAM_TRY(launch(1, rows_main, p->vn - rows_main));
         } else {

@@ -489,3 +489,20 @@ def test_small_pool_k_split_scan_is_bit_identical(gpu, n, d, m, k):
     assert sims.tobytes() == o_sim[:, :kk].tobytes()
     assert rows[0, 0] == 0
     pool.close()
+
+
+def test_narrow_gemm_tiles_for_129_to_192_queries(gpu):
+    """k_gemm_dma<2,2,TJ=1> (128 x 64 tiles: three 64-query column blocks instead of two padded
+    128-query ones) — same (k, k+4) operand pairing and chunk folds, bit-identical to the oracle;
+    a pool with a partial last row tile and more rows than one wave of tiles."""
+    rs = np.random.RandomState(192)
+    n, d, m = 70_001, 512, 180
+    X = rs.rand(n, d).astype(np.float32) - 0.2
+    Q = rs.rand(m, d).astype(np.float32) - 0.2
+    pool = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = pool.search_batch(Q, 3)
+    assert gpu.cslam_pool_scan_kernel(pool.handle).decode().endswith("TJ=1>")
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 3)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    pool.close()
