@@ -56,7 +56,10 @@ typedef struct cslam_pool cslam_pool_t;
 int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_t** out);
 int cslam_pool_destroy(cslam_pool_t* pool);
 
-/* add_item (nns_matching.py:23-42), batched: append n_rows dense rows [n_rows][dim]. */
+/* add_item (nns_matching.py:23-42), batched: append n_rows dense rows [n_rows][dim].  `rows` is
+ * copied before the call returns (the caller may reuse it at once); small appends are applied on the
+ * handle's stream without a host synchronisation — every later call on the handle is ordered behind
+ * them, and an error of the append itself surfaces with the next synchronising call. */
 int cslam_pool_add(cslam_pool_t* pool, const float* rows, int64_t n_rows);
 /* same, rows already in HBM; row_stride in floats (>= dim). Async on `stream`. */
 int cslam_pool_add_dev(cslam_pool_t* pool, const float* rows_dev, int64_t n_rows,
