@@ -459,3 +459,43 @@ print(json.dumps(out))
     want = [int(x) for x in np.nonzero(g("rounded"))[0]]
     assert out["r1"] == want and out["r2"] == want
     np.testing.assert_allclose(out["trace2"], g("lambda_trace"), atol=1e-9)
+
+
+def test_persistent_solver_next_to_a_vpr_like_backbone_stream(gpu):
+    """cfg5's situation: the learned front end (PyTorch-ROCm convolutions / GEMMs with fat
+    workgroups, LDS and registers of their own) keeps the CUs busy on ITS stream while the
+    persistent Fiedler kernel wants all of its workgroups resident.  Whatever the scheduler does —
+    the solver runs beside it or takes the timeout → graph-path recovery — the selection must
+    equal the one computed on an idle GPU, nothing may hang, and the handle must stay usable."""
+    torch = pytest.importorskip("torch")
+    from mac_bench_util import cfg3_graph, greedy_w
+    from cslam_amd.mac.mac import MAC
+    n, fixed, cand = cfg3_graph(poses_per_robot=8000, nb_candidates=40_000, seed=5)
+    w0 = greedy_w(cand, 250)
+    mac = MAC(fixed, cand, n)
+    with redirect_stdout(io.StringIO()):
+        base_round, base_relaxed, base_upper = mac.fw_subset(w0, 250, max_iters=8)
+    lam_idle, _ = mac.evaluate_fiedler_pair(w0)
+    mac.close()
+
+    side = torch.cuda.Stream()
+    a = torch.randn((6144, 6144), device="cuda", dtype=torch.float16)
+    img = torch.randn((64, 64, 112, 112), device="cuda", dtype=torch.float16)
+    wconv = torch.randn((128, 64, 3, 3), device="cuda", dtype=torch.float16)
+    overlapped = 0
+    for _ in range(3):
+        with torch.cuda.stream(side):                 # a few hundred ms of back-to-back heavy kernels
+            for _ in range(300):
+                a2 = a @ a
+                y = torch.nn.functional.conv2d(img, wconv, padding=1)
+        mac = MAC(fixed, cand, n)
+        with redirect_stdout(io.StringIO()):
+            rounded, relaxed, upper = mac.fw_subset(w0, 250, max_iters=8)
+        lam, _ = mac.evaluate_fiedler_pair(w0)
+        overlapped += int(not side.query())           # the backbone was still running meanwhile
+        mac.close()
+        np.testing.assert_array_equal(rounded, base_round)
+        np.testing.assert_allclose(relaxed, base_relaxed, atol=1e-9)
+        assert abs(upper - base_upper) < 1e-9 and abs(lam - lam_idle) < 1e-12
+        side.synchronize()
+    assert overlapped >= 1, "the side stream always finished before the solves: nothing overlapped"
