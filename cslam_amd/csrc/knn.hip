@@ -792,6 +792,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     f32x4 bc[16], bn[16];
     float ss[16];  // BEST: sum-of-squares chains of norm lanes 4i + g of query r
     float rnq = 0.f;
+    float rv0 = 0.f, rv1 = 0.f;  // BEST: 1/||x|| of the panel's rows, one row per lane and register
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i] = 0.f;
     DmaCursor ic;  // issue cursor: runs NST stages ahead of the consumer
@@ -834,6 +835,19 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             // the next panel); it is waited for at the end of this slice
 #pragma unroll
             for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            if (BEST) {
+                // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l fetches rows lo + l
+                // and lo + 64 + l (clamped into the window).  Issued IN FRONT of the B loads, so
+                // the counted wait for those at the end of the slice covers these two as well.
+                // (Ordinary loads in the epilogue made hipcc wait vmcnt(0) 32 times per panel:
+                // 32 dependent memory round trips with the ring drained.)
+                int64_t i0 = lo + lane, i1 = lo + 64 + lane;
+                i0 = i0 < n ? i0 : n - 1;
+                i1 = i1 < n ? i1 : n - 1;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(rv0) : "v"(rnx + i0) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(rv1) : "v"(rnx + i1) : "memory");
+                bump(2);
+            }
             load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
             bump(16);
             yq = 0;
@@ -879,6 +893,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             }
             wait_vm_dyn(yq);
             tie16(bn);
+            if (BEST) asm volatile("" : "+v"(rv0), "+v"(rv1));
         }
         if (norms && p == p_begin) {
             // butterfly 32, 16, 8, 4 of the norm lanes = register index xor 8, 4, 2, 1;
@@ -906,8 +921,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                     const int64_t r0 = lo + 16 * s + 4 * g;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        const float rn = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
                         if (r0 + e < hi) {
-                            const float sim = (tot[s][e] * rnx[r0 + e]) * rnq;
+                            const float sim = (tot[s][e] * rn) * rnq;
                             const uint64_t c = make_comp(sim, row0 + (uint32_t)(r0 + e));
                             if (two && r0 + e >= split)
                                 best_c = c > best_c ? c : best_c;
