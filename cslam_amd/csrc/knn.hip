@@ -683,26 +683,30 @@ __device__ inline void wait_vm_dyn(int n) {
 #undef CSLAM_W
 }
 
-// 16 B fragments (one 256-float slice of the lane's query column) by inline-asm loads; the
-// registers may only be read behind a counted wait followed by tie16()
-__device__ inline void load_b16(f32x4 (&b)[16], const float* qrow) {
+// NB B fragments (one KW-float slice of the lane's query column, NB = KW / 16) by inline-asm
+// loads; the registers may only be read behind a counted wait followed by tie_b()
+template <int NB>
+__device__ inline void load_b(f32x4 (&b)[NB], const float* qrow) {
 #define CSLAM_LB(I)                                                                     \
-    asm volatile("global_load_dwordx4 %0, %1, off offset:" #I "*64" : "=v"(b[I]) : "v"(qrow) : "memory");
+    if (I < NB)                                                                         \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:" #I "*64" : "=v"(b[I < NB ? I : 0]) : "v"(qrow) : "memory");
     CSLAM_LB(0) CSLAM_LB(1) CSLAM_LB(2) CSLAM_LB(3) CSLAM_LB(4) CSLAM_LB(5) CSLAM_LB(6) CSLAM_LB(7)
     CSLAM_LB(8) CSLAM_LB(9) CSLAM_LB(10) CSLAM_LB(11) CSLAM_LB(12) CSLAM_LB(13) CSLAM_LB(14) CSLAM_LB(15)
 #undef CSLAM_LB
 }
-__device__ inline void tie16(f32x4 (&b)[16]) {
-    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]),
-                      "+v"(b[6]), "+v"(b[7]));
-    asm volatile("" : "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]),
-                      "+v"(b[14]), "+v"(b[15]));
+template <int NB>
+__device__ inline void tie_b(f32x4 (&b)[NB]) {
+#pragma unroll
+    for (int i = 0; i < NB; i += 4)
+        asm volatile("" : "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), "+v"(b[i + 3]));
 }
+__device__ inline void load_b16(f32x4 (&b)[16], const float* qrow) { load_b<16>(b, qrow); }
+__device__ inline void tie16(f32x4 (&b)[16]) { tie_b<16>(b); }
 
 struct DmaCursor {   // position of a stage in a wave's work list
     int64_t lo;      // first row of the panel
     int rows;        // rows of the panel (<= 16 * NS)
-    int ns;          // strips of the panel
+    int ns;          // stages per slice of the panel
     int p;           // panel index
     int kc;          // 256-float slice
     int s;           // strip inside the panel
@@ -725,7 +729,25 @@ struct DmaCursor {   // position of a stage in a wave's work list
 //   loads, ~1.5 us of memory-side latency each) cost 7.4 us against 4.5 us for the select launch
 //   behind the scan (265.9 vs 263.0 us per step); with a release fence per block (buffer_wbl2)
 //   +8 us more.
-template <int NS, int NW, int NST, int AUX, bool BEST>
+//   Slice width KW (template): 256 floats = one row per DMA instruction, as described above.
+//   KW = 128 / 64 (descriptor lengths that are a multiple of 128 / 64 but not of 256: the 128-d
+//   descriptors of the reference's own configuration): one DMA instruction moves R = 256 / KW
+//   ROWS x KW floats (lanes [k 64/R, (k+1) 64/R) fetch row k of the piece), a stage is 16 R rows
+//   = R row groups of 16, a panel is still 128 rows = 8 row groups with one accumulator each.
+//   The 16-B segments of row k of a piece are XOR-k swizzled on the SOURCE side (LDS position j
+//   holds global segment j ^ k) and the piece pitch is 1024 + 32 B (R <= 2) or 1024 + 64 B
+//   (R = 4), so that the 16 lanes of a ds_read_b128 pass — 16 rows at one k offset — hit 16
+//   different 16-B slots.  Same chain order, same folds: same bits.
+template <int KW>
+struct DmaGeom {
+    static constexpr int R = 256 / KW;                       // rows per DMA instruction
+    static constexpr int NB = KW / 16;                       // B fragments per slice
+    static constexpr int kPiece = 1024 + (R == 4 ? 64 : 32); // LDS bytes per piece
+    static constexpr int kStage = 16 * kPiece;               // 16 R rows x KW floats
+    static constexpr int kFold = 512 / KW;                   // slices per 512-float chunk
+};
+
+template <int NS, int NW, int NST, int AUX, bool BEST, int KW = 256>
 __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
                                                       int64_t n, int dp,
                                                       const float* __restrict__ Q, int64_t q_stride,
@@ -737,6 +759,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       int64_t cand_stride,
                                                       float* __restrict__ rnq_out,
                                                       int64_t split, uint64_t* __restrict__ cand_c) {
+    using GM = DmaGeom<KW>;
+    constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
+    static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     // the query norms are computed here when the epilogue needs them (BEST) or when the caller
     // skipped the staging kernel and wants them for the select (rnq_out)
@@ -745,8 +770,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int w = blockIdx.x * NW + wave;
-    char* ring = dma_lds + wave * NST * kDmaStageB;
-    const int nkc = dp >> 8;
+    char* ring = dma_lds + wave * NST * kStage;
+    const int nkc = dp / KW;
     const int p_begin = w * ppw;
     int p_end = p_begin + ppw;
     if (p_end > n_panels) p_end = n_panels;
@@ -762,7 +787,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         c.lo = panel_lo(p);
         const int64_t hi = panel_lo(p + 1);
         c.rows = (int)(hi - c.lo);
-        c.ns = (c.rows + 15) >> 4;
+        c.ns = (c.rows + 16 * R - 1) / (16 * R);   // stages per slice
         c.kc = 0;
         c.s = 0;
     };
@@ -772,24 +797,42 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         if (++c.kc < nkc) return;
         panel(c, c.p + 1);  // may run to p_end: the caller checks before issuing
     };
-    // one DMA instruction per valid row of the strip: lane l moves bytes [16l, 16l+16) of the
-    // row's slice, the LDS image of a piece is linear (base + 16 * lane)
+    // one DMA instruction per piece (R rows) of the stage: the LDS image of a piece is linear
+    // (base + 16 * lane).  R = 1: lane l moves bytes [16l, 16l+16) of the row's slice.  R > 1:
+    // lane l moves segment (l mod 64/R) ^ k of row k = l / (64/R) of the piece; a row past the
+    // end of the stage repeats the stage's last row (its results are never looked at).
+    const int sub = R == 1 ? 0 : lane / (64 / R);
+    const int seg = R == 1 ? lane : ((lane & (64 / R - 1)) ^ sub);
+    const int64_t sub_off = (int64_t)sub * xs;
     auto issue = [&](const DmaCursor& c, char* slot) {
-        int cnt = c.rows - 16 * c.s;
-        cnt = cnt > 16 ? 16 : cnt;
-        const float* src = X + (c.lo + 16 * c.s) * xs + c.kc * 256 + lane * 4;
+        int cnt = c.rows - 16 * R * c.s;   // valid rows of the stage (>= 1)
+        cnt = cnt > 16 * R ? 16 * R : cnt;
+        const int np = (cnt + R - 1) / R;  // pieces
+        const float* src = X + (c.lo + 16 * R * c.s) * xs + c.kc * KW + seg * 4;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr)
-            if (rr < cnt)
+            if (rr < np) {
+                const float* a = src + (int64_t)(R * rr) * xs;
+                if (R > 1) {
+                    if (R * rr + R <= cnt) {
+                        a += sub_off;
+                    } else {  // ragged last piece
+                        const int k = R * rr + sub < cnt ? sub : cnt - 1 - R * rr;
+                        a += (int64_t)k * xs;
+                    }
+                }
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + rr * xs),
-                    (__attribute__((address_space(3))) void*)(slot + rr * kDmaPieceB), 16, 0, AUX);
-        return cnt;
+                    (const __attribute__((address_space(1))) void*)a,
+                    (__attribute__((address_space(3))) void*)(slot + rr * kPiece), 16, 0, AUX);
+            }
+        return np;
     };
+    // reader side: row r of row group h sits in piece (16 h + r) / R as row r % R
+    const int rd_off = (r / R) * kPiece + (r % R) * (KW * 4) + ((g ^ (r % R)) * 16);
 
     // this lane's B fragment column (rows past q_rows repeat the last query: never stored)
     const float* qrow = Q + (int64_t)(r < q_rows ? r : q_rows - 1) * q_stride + 4 * g;
-    f32x4 bc[16], bn[16];
+    f32x4 bc[NB], bn[NB];
     float ss[16];  // BEST: sum-of-squares chains of norm lanes 4i + g of query r
     float rnq = 0.f;
     float rv0 = 0.f, rv1 = 0.f;  // BEST: 1/||x|| of the panel's rows, one row per lane and register
@@ -806,13 +849,13 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         for (int i = 0; i < NST; ++i) y[i] += k;
         yq += k;
     };
-    load_b16(bn, qrow);
+    load_b<NB>(bn, qrow);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tie16(bn);
+    tie_b<NB>(bn);
 #pragma unroll
     for (int i = 0; i < NST; ++i)
         if (ic.p < p_end) {
-            const int c = issue(ic, ring + i * kDmaStageB);
+            const int c = issue(ic, ring + i * kStage);
             bump(c);
             y[i] = 0;
             advance(ic);
@@ -823,7 +866,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t lo = panel_lo(p);
         const int64_t hi = panel_lo(p + 1);
-        const int ns = (int)((hi - lo + 15) >> 4);
+        const int ns = (int)((hi - lo + 15) >> 4);   // row groups of the panel
         f32x4 acc[NS], tot[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -834,7 +877,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             // bn holds B(kc), landed and tied: hand it over and start B(kc+1) (slice 0 again for
             // the next panel); it is waited for at the end of this slice
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bc[i] = bn[i];
+            for (int i = 0; i < NB; ++i) bc[i] = bn[i];
             if (BEST) {
                 // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l fetches rows lo + l
                 // and lo + 64 + l (clamped into the window).  Issued IN FRONT of the B loads, so
@@ -848,27 +891,38 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                 asm volatile("global_load_dword %0, %1, off" : "=v"(rv1) : "v"(rnx + i1) : "memory");
                 bump(2);
             }
-            load_b16(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * 256);
-            bump(16);
+            load_b<NB>(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * KW);
+            bump(NB);
             yq = 0;
             if (norms && p == p_begin) {
+                // fragment i of slice kc holds the floats of norm lane 4 (i + NB (kc mod R)) + g
+                const int q4 = R == 1 ? 0 : (kc & (R - 1));
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
+                for (int h = 0; h < R; ++h)
+                    if (q4 == h) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ss[i] = __builtin_fmaf(bc[i][j], bc[i][j], ss[i]);
+                        for (int i = 0; i < NB; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                ss[h * NB + i] = __builtin_fmaf(bc[i][j], bc[i][j], ss[h * NB + i]);
+                    }
             }
+            const bool fold = ((kc + 1) & (GM::kFold - 1)) == 0 || kc + 1 == nkc;  // end of a 512-float chunk / of the row
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s < ns) {
-                    char* sp = ring + slot * kDmaStageB;
+            for (int s = 0; s < NS / R; ++s) {
+                if (R * s < ns) {
+                    char* sp = ring + slot * kStage;
                     int yc = y[0];
 #pragma unroll
                     for (int i = 1; i < NST; ++i) yc = slot == i ? y[i] : yc;
                     wait_vm_dyn(yc);  // this stage's pieces have landed
                     f32x4 a[16];
-                    const char* ap = sp + r * kDmaPieceB + g * 16;
+                    const char* ap = sp + rd_off;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 64);
+                    for (int h = 0; h < R; ++h)
+#pragma unroll
+                        for (int i = 0; i < NB; ++i)
+                            a[h * NB + i] = *reinterpret_cast<const f32x4*>(ap + h * (16 / R) * kPiece + i * 64);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     if (ic.p < p_end) {  // the slot is free again: refill it NST stages ahead
@@ -879,20 +933,25 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                         for (int i = 0; i < NST; ++i) y[i] = slot == i ? 0 : y[i];
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
+                    for (int h = 0; h < R; ++h) {
+                        if (R == 1 || R * s + h < ns) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bc[i][j], acc[s],
-                                                                          0, 0, 0);
-                    if ((kc & 1) || kc + 1 == nkc) {  // end of a 512-float chunk / of the row
-                        tot[s] = tot[s] + acc[s];
-                        acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[R * s + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        a[h * NB + i][j], bc[i][j], acc[R * s + h], 0, 0, 0);
+                            if (fold) {
+                                tot[R * s + h] = tot[R * s + h] + acc[R * s + h];
+                                acc[R * s + h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
                     }
                     slot = slot + 1 == NST ? 0 : slot + 1;
                 }
             }
             wait_vm_dyn(yq);
-            tie16(bn);
+            tie_b<NB>(bn);
             if (BEST) asm volatile("" : "+v"(rv0), "+v"(rv1));
         }
         if (norms && p == p_begin) {
@@ -1720,7 +1779,7 @@ bool prof_take(cslam_pool* p) {
 // the older kernels, =dma forces it below its switch-over size)
 bool dma_scan_applies(const cslam_pool* p) {
     static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
-    if (p->dp % 256 != 0 || p->vn <= 0) return false;
+    if (p->dp % 64 != 0 || p->vn <= 0) return false;
     if (kern_env && strcmp(kern_env, "dma") == 0) return true;
     if (kern_env && (strcmp(kern_env, "ring") == 0 || strcmp(kern_env, "lds") == 0 ||
                      strcmp(kern_env, "pc") == 0))
@@ -1733,7 +1792,7 @@ bool dma_scan_applies(const cslam_pool* p) {
 // k_scan_dma.
 bool ks_scan_applies(const cslam_pool* p, int m) {
     static const bool ks_env = !(getenv("CSLAM_SCAN_KSPLIT") && atoi(getenv("CSLAM_SCAN_KSPLIT")) == 0);
-    if (!ks_env || m > 16 || !dma_scan_applies(p)) return false;
+    if (!ks_env || m > 16 || !dma_scan_applies(p) || p->dp % 256 != 0) return false;
     const int64_t strips = (p->vn + 15) / 16;
     const int nchunks = (p->dp / 256 + 1) / 2;
     return strips <= p->cus && nchunks >= 4 && nchunks <= kKsMaxChunks;
@@ -1754,7 +1813,8 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
     if (best && cand_stride < n_panels) return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
     const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
-    const size_t lds = (size_t)NW * NST * kDmaStageB;
+    // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
+    const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
     if (cand_c == nullptr || split < 0) {
         split = INT64_MAX;  // one window
         cand_c = nullptr;
@@ -1762,37 +1822,46 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     // pool rows are read once per search: non-temporal unless the pool could stay resident
     // in the 256-MiB Infinity Cache between searches
     const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
-#define CSLAM_DMA_LAUNCH(AUX, BEST)                                                               \
+#define CSLAM_DMA_LAUNCH(AUX, BEST, KW)                                                           \
     do {                                                                                          \
+        const size_t lds = (size_t)NW * NST * DmaGeom<KW>::kStage;                                \
         static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
         if (!attr_set[p->device & 63]) {                                                          \
-            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST>,    \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST, KW>, \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
             attr_set[p->device & 63] = true;                                                      \
         }                                                                                         \
-        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST>), dim3(blocks), dim3(NW * 64), lds, \
-                           st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride, q_rows, \
-                           m, dots, dots_stride, (int)n_panels, (int)ppw, p->inv_norm + p->v0,    \
-                           (uint32_t)p->v0, cand, cand_stride, rnq_out, split, cand_c);           \
+        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST, KW>), dim3(blocks), dim3(NW * 64), \
+                           lds, st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride,    \
+                           q_rows, m, dots, dots_stride, (int)n_panels, (int)ppw,                 \
+                           p->inv_norm + p->v0, (uint32_t)p->v0, cand, cand_stride, rnq_out,      \
+                           split, cand_c);                                                        \
     } while (0)
+#define CSLAM_DMA_LAUNCH_KW(AUX, BEST)                   \
+    do {                                                 \
+        if (kw == 256) CSLAM_DMA_LAUNCH(AUX, BEST, 256); \
+        else if (kw == 128) CSLAM_DMA_LAUNCH(AUX, BEST, 128); \
+        else CSLAM_DMA_LAUNCH(AUX, BEST, 64);            \
+    } while (0)
+    static const char* const names[3][4] = {
+        {"k_scan_dma<NS=8,NW=4,NST=2,nt,best>", "k_scan_dma<NS=8,NW=4,NST=2,best>",
+         "k_scan_dma<NS=8,NW=4,NST=2,nt>", "k_scan_dma<NS=8,NW=4,NST=2>"},
+        {"k_scan_dma<NS=8,NW=4,NST=2,nt,best,KW=128>", "k_scan_dma<NS=8,NW=4,NST=2,best,KW=128>",
+         "k_scan_dma<NS=8,NW=4,NST=2,nt,KW=128>", "k_scan_dma<NS=8,NW=4,NST=2,KW=128>"},
+        {"k_scan_dma<NS=8,NW=4,NST=2,nt,best,KW=64>", "k_scan_dma<NS=8,NW=4,NST=2,best,KW=64>",
+         "k_scan_dma<NS=8,NW=4,NST=2,nt,KW=64>", "k_scan_dma<NS=8,NW=4,NST=2,KW=64>"}};
+    const int ki = kw == 256 ? 0 : (kw == 128 ? 1 : 2);
     if (best) {
-        if (nt) {
-            CSLAM_DMA_LAUNCH(2, true);
-            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt,best>";
-        } else {
-            CSLAM_DMA_LAUNCH(0, true);
-            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,best>";
-        }
+        if (nt) CSLAM_DMA_LAUNCH_KW(2, true);
+        else CSLAM_DMA_LAUNCH_KW(0, true);
+        p->last_scan_kernel = names[ki][nt ? 0 : 1];
     } else {
-        if (nt) {
-            CSLAM_DMA_LAUNCH(2, false);
-            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2,nt>";
-        } else {
-            CSLAM_DMA_LAUNCH(0, false);
-            p->last_scan_kernel = "k_scan_dma<NS=8,NW=4,NST=2>";
-        }
+        if (nt) CSLAM_DMA_LAUNCH_KW(2, false);
+        else CSLAM_DMA_LAUNCH_KW(0, false);
+        p->last_scan_kernel = names[ki][nt ? 2 : 3];
     }
+#undef CSLAM_DMA_LAUNCH_KW
 #undef CSLAM_DMA_LAUNCH
     CSLAM_HIP_TRY(hipGetLastError());
     // BEST: candidates per query = waves that hold panels

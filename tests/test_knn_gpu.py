@@ -333,6 +333,24 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
     (20011, 512, 5, 1),       # k = 1, partial strips, 5 of 16 query columns valid
     (20000, 250, 7, 1),       # k = 1, dim padded to 256: staged queries
     (140000, 256, 1, 1),      # k = 1, two panels per wave (query norm only from the first)
+    # slice width 128 (dim % 128 == 0, % 256 != 0): two rows per DMA instruction
+    (20011, 128, 16, 1),      # the reference's own descriptor length; ragged panels, odd tails
+    (20011, 128, 5, 10),
+    (300000, 128, 16, 1),     # three panels per wave
+    (33, 128, 3, 1),          # one full stage + a one-row stage
+    (1, 128, 1, 1),
+    (9000, 384, 7, 1),        # three slices: the 512-float fold falls after the row's end
+    (9000, 640, 16, 4),       # five slices: one whole chunk + a quarter
+    (5000, 120, 9, 1),        # dim padded to 128: staged queries
+    # slice width 64: four rows per DMA instruction
+    (20011, 64, 16, 1),
+    (20011, 64, 4, 10),
+    (600000, 64, 16, 1),      # five panels per wave
+    (67, 64, 2, 1),           # 64 rows + a three-row piece
+    (2, 64, 1, 1),
+    (7001, 192, 16, 1),       # three slices
+    (7001, 320, 3, 7),        # five slices
+    (4000, 576, 11, 1),       # nine slices: 512 + 64
 ])
 def test_dma_scan_matches_oracle(gpu, n, d, m, k):
     """k_scan_dma (the default dots kernel from 16384 rows when dim % 256 == 0) against the C
@@ -404,7 +422,11 @@ def test_full_size_properties(gpu):
     (3000, 256, 9, 1500),         # small pool: fewer panels than waves
     (70, 256, 16, 64),            # one strip per panel, partial last strip
     (2500, 1024, 40, 2400),       # > 16 queries: one launch per 16
-    (1200, 48, 7, 1000),          # dim % 256 != 0: two range searches behind the same entry point
+    (1200, 48, 7, 1000),          # dim % 64 != 0: two range searches behind the same entry point
+    (18000, 128, 16, 17990),      # slice width 128
+    (75, 128, 16, 70),
+    (18000, 64, 16, 17999),       # slice width 64
+    (5000, 192, 3, 2),
 ])
 def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     """cslam_pool_search_best_split_dev: best row before `split` and best row from `split` on in

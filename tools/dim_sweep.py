@@ -10,7 +10,8 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 BYTES = int(sys.argv[1]) if len(sys.argv) > 1 else 1_638_400_000
-for D in (64, 128, 192, 256, 384, 512, 768, 1024, 2048, 4096, 8192):
+DIMS = [int(a) for a in sys.argv[2:]] or [64, 128, 192, 256, 384, 512, 768, 1024, 2048, 4096, 8192]
+for D in DIMS:
     n = BYTES // (D * 4)
     X = torch.rand((n, D), device=dev, generator=g)
     pool = NearestNeighborsMatching(dim=D, capacity_hint=n)
