@@ -2334,8 +2334,14 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
     p->dim = dim;
     p->dp = (int)pad16(dim);
     {
+        // Row stride.  A stride that is a multiple of 4 KiB (1024-, 2048-, 4096-, 8192-d rows) lines
+        // the 16 rows of a scan stage up on the same few HBM channels: 512 B of padding per row
+        // (never read) spreads them — same process, alternating pools, 16 best-match queries over
+        // 1.6 GB: 4096-d 0.2615 -> 0.2555 ms, 1024-d 0.289 -> 0.2575, 2048-d 0.2735 -> 0.2558,
+        // 8192-d 0.2825 -> 0.2629 (tools/pad_ab.py, profiles/r02_pad_ab.txt).  CSLAM_ROW_PAD
+        // (floats) overrides, 0 = dense rows.
         const char* e = getenv("CSLAM_ROW_PAD");
-        int64_t pad = e ? atoll(e) : 0;
+        int64_t pad = e ? atoll(e) : (((int64_t)p->dp * 4) % 4096 == 0 ? 128 : 0);
         p->xs = p->dp + (pad > 0 ? pad16(pad) : 0);
     }
     p->device = device_id;
