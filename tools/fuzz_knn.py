@@ -21,7 +21,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
-    dim = int(rs.choice([1, 3, 16, 17, 100, 128, 255, 256, 511, 512, 1000, 2048, 4096]))
+    dim = int(rs.choice([1, 3, 16, 17, 64, 100, 120, 128, 192, 255, 256, 320, 384, 511, 512, 640, 1000, 1024, 2048, 4096]))
     n = int(rs.choice([1, 2, 15, 16, 17, 127, 128, 129, 1000, 4097, 16383, 16384, 20000, 33001, 70000]))
     if n * dim > 40_000_000:
         n = 40_000_000 // dim
