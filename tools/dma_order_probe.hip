@@ -121,6 +121,8 @@ __global__ void k_fill(float* X, size_t n) {
     if (i < n) X[i] = (float)((i * 2654435761ull) & 0xFFFF) * 1e-5f;
 }
 
+static int64_t g_xs = 4096;   // row stride in floats (argv[1] = padding floats per row)
+
 template <int NW, int NST, int AUX>
 void run(const char* name, const float* X, int64_t n, int dp, int S, int P, int mode, int cus, float* sink, int d1 = 0, int d2 = 0) {
     const size_t lds = (size_t)NW * NST * kStageB;
@@ -132,7 +134,7 @@ void run(const char* name, const float* X, int64_t n, int dp, int S, int P, int 
     const int reps = 12;
     for (int i = 0; i < reps + 3; ++i) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_stream<NW, NST, AUX>), dim3(cus), dim3(NW * 64), lds, 0, X, (int64_t)dp, n, dp, S, P, mode,
+        hipLaunchKernelGGL((k_stream<NW, NST, AUX>), dim3(cus), dim3(NW * 64), lds, 0, X, g_xs, n, dp, S, P, mode,
                            cus * NW, sink, d1, d2);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -157,7 +159,7 @@ void run_half(const char* name, const float* X, int64_t n, int dp, int S, int cu
     const int reps = 12;
     for (int i = 0; i < reps + 3; ++i) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_stream_half<NW, NST, AUX>), dim3(cus), dim3(NW * 64), lds, 0, X, (int64_t)dp, n, dp, S,
+        hipLaunchKernelGGL((k_stream_half<NW, NST, AUX>), dim3(cus), dim3(NW * 64), lds, 0, X, g_xs, n, dp, S,
                            cus * NW, sink, d1, d2);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -171,18 +173,28 @@ void run_half(const char* name, const float* X, int64_t n, int dp, int S, int cu
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int64_t n = 100000 / 16 * 16;
     const int dp = 4096;
+    const int pad = argc > 1 ? atoi(argv[1]) : 0;
+    g_xs = dp + pad;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     float *X, *sink;
-    CK(hipMalloc(&X, (size_t)n * dp * 4));
+    CK(hipMalloc(&X, (size_t)n * g_xs * 4));
     CK(hipMalloc(&sink, 64));
-    k_fill<<<(unsigned)(((size_t)n * dp + 255) / 256), 256>>>(X, (size_t)n * dp);
+    k_fill<<<(unsigned)(((size_t)n * g_xs + 255) / 256), 256>>>(X, (size_t)n * g_xs);
     CK(hipDeviceSynchronize());
-    printf("n=%lld dp=%d cus=%d\n", (long long)n, dp, cus);
+    printf("n=%lld dp=%d row stride=%lld floats cus=%d\n", (long long)n, dp, (long long)g_xs, cus);
+    if (argc > 1) {   // padded rows: the short list
+        for (int rep = 0; rep < 3; ++rep) {
+            run<4, 2, 2>("shipped order (P=1,S=8) nt", X, n, dp, 8, 1, 0, cus, sink);
+            run<4, 2, 2>("row-contiguous (P=16) nt", X, n, dp, 8, 16, 0, cus, sink);
+            run<4, 2, 2>("nt, gap 512 + mfma 2048", X, n, dp, 8, 1, 0, cus, sink, 8, 32);
+        }
+        return 0;
+    }
     run<4, 2, 2>("shipped order (P=1,S=8) nt", X, n, dp, 8, 1, 0, cus, sink);
     run<4, 2, 0>("shipped order (P=1,S=8)", X, n, dp, 8, 1, 0, cus, sink);
     run<4, 2, 2>("P=2 S=8 nt", X, n, dp, 8, 2, 0, cus, sink);
