@@ -2332,7 +2332,18 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
     CSLAM_HIP_TRY(hipSetDevice(device_id));
     cslam_pool* p = new cslam_pool();
     p->dim = dim;
-    p->dp = (int)pad16(dim);
+    {
+        // padded row length: a multiple of 64 floats, the LDS-DMA scan's narrowest slice (16 — the
+        // MFMA k-group — for descriptors of <= 16 floats, where 64 would quadruple the pool).
+        // Zero padding never changes a bit of the result: fmaf(0, 0, acc) = acc, and a 512-float
+        // fold boundary is never crossed by the extra zeros.  Payload TB/s of a 16-query
+        // best-match step, 16- vs 64-float alignment: 100-d 2.69 -> 4.44, 300-d 3.59 -> 5.68,
+        // 1000-d 3.79 -> 5.92, 33-d 1.33 -> 2.34 (profiles/r02_dim_align.txt).
+        // CSLAM_DIM_ALIGN=16 keeps the tight padding (register-ring scan for such lengths).
+        const char* e = getenv("CSLAM_DIM_ALIGN");
+        const int al = (e && atoi(e) == 16) || dim <= 16 ? 16 : 64;
+        p->dp = (int)((dim + al - 1) / al * al);
+    }
     {
         // Row stride.  A stride that is a multiple of 4 KiB (1024-, 2048-, 4096-, 8192-d rows) lines
         // the 16 rows of a scan stage up on the same few HBM channels: 512 B of padding per row
