@@ -2,7 +2,8 @@
 launches per shape, every result compared bit for bit with the first one (an intermittent race in
 the hand-counted vmcnt / LDS-DMA pipelines would show as a flipped bit sooner or later) and the
 first one with the oracle.  Shapes cover k_scan_dma (big pool), k_scan_dma_ks (small pool, long
-descriptors), the split best-match scan, the register-ring scan (dim % 256 != 0) and k = 10."""
+descriptors), the split best-match scan, the narrow-slice variants (128 / 64 floats per slice), a ragged length
+(staged queries), the register-ring scan (dim <= 16) and k = 10."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,9 @@ L = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 bad = 0
 for (n, d, m, k, split) in [(100_000, 4096, 16, 1, -1), (100_000, 4096, 16, 1, 99_990), (3000, 4096, 16, 1, -1),
-                            (20_000, 512, 16, 10, -1), (5000, 100, 7, 1, -1), (900, 2048, 3, 5, -1)]:
+                            (20_000, 512, 16, 10, -1), (5000, 100, 7, 1, -1), (900, 2048, 3, 5, -1),
+                            (400_000, 128, 16, 1, -1), (400_000, 128, 16, 1, 399_990), (300_000, 64, 16, 1, -1),
+                            (50_000, 384, 9, 10, -1), (3000, 10, 5, 3, -1)]:
     rs = np.random.RandomState(n + d)
     X = rs.rand(n, d).astype(np.float32); Q = rs.rand(m, d).astype(np.float32)
     pool = NearestNeighborsMatching(dim=d, capacity_hint=n); pool.add_items(X, list(range(n)))
