@@ -11,6 +11,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only; nothing links against librccl at build time
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -92,6 +94,13 @@ __global__ __launch_bounds__(256) void k_replicate(const T* __restrict__ send, T
     if (i >= per_rank) return;
     T* dst = recv + (int64_t)blockIdx.y * per_rank;
     if (dst != send) dst[i] = send[i];
+}
+
+// measurement aid (CSLAM_LOOPBACK_HOG="workgroups,microseconds"): workgroups that hold a CU each for
+// a while, the way a collective's kernel does while it waits for its peers
+__global__ __launch_bounds__(256) void k_hog(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 }  // namespace
@@ -189,6 +198,12 @@ int loopback_allgather(void* user, const void* send_dev, void* recv_dev, int64_t
     } else {
         hipLaunchKernelGGL((k_replicate<uint8_t>), dim3((unsigned)((bytes + 255) / 256), nranks),
                            dim3(256), 0, st, (const uint8_t*)send_dev, (uint8_t*)recv_dev, bytes, nranks);
+    }
+    static const char* hog = getenv("CSLAM_LOOPBACK_HOG");
+    if (hog) {
+        int wgs = 0, us = 0;
+        if (sscanf(hog, "%d,%d", &wgs, &us) == 2 && wgs > 0 && us > 0)
+            hipLaunchKernelGGL(k_hog, dim3(wgs), dim3(256), 0, st, (long long)us * 100);  // 100 MHz clock
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

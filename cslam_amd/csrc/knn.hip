@@ -758,7 +758,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       uint64_t* __restrict__ cand,
                                                       int64_t cand_stride,
                                                       float* __restrict__ rnq_out,
-                                                      int64_t split, uint64_t* __restrict__ cand_c) {
+                                                      int64_t split, uint64_t* __restrict__ cand_c,
+                                                      int unit) {
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
     static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
@@ -780,8 +781,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     // panel p = rows [p q + min(p, rem), ...): n = q n_panels + rem, the first rem panels one row
     // longer.  (floor(p n / n_panels) costs two 64-bit divisions, inlined at every one of the
     // unrolled sites that advance the issue cursor: a third of the kernel's code.)
-    const int rows_q = (int)(n / n_panels), rows_rem = (int)(n - (int64_t)rows_q * n_panels);
-    auto panel_lo = [&](int p) { return (int64_t)p * rows_q + (p < rows_rem ? p : rows_rem); };
+    // With unit = 16 the same split is made in whole 16-row strips (the last panel ends at n):
+    // no panel carries a nearly empty strip through all its slices.
+    const int64_t n_units = (n + unit - 1) / unit;
+    const int rows_q = (int)(n_units / n_panels), rows_rem = (int)(n_units - (int64_t)rows_q * n_panels);
+    auto panel_lo = [&](int p) {
+        const int64_t v = ((int64_t)p * rows_q + (p < rows_rem ? p : rows_rem)) * unit;
+        return v < n ? v : n;
+    };
     auto panel = [&](DmaCursor& c, int p) {
         c.p = p;
         c.lo = panel_lo(p);
@@ -1805,16 +1812,40 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
                     int64_t* n_panels_out, hipStream_t st, float* rnq_out = nullptr,
                     int64_t split = -1, uint64_t* cand_c = nullptr) {
     constexpr int NS = 8, NW = 4, NST = 2;
-    const int64_t nw = (int64_t)p->cus * NW;
+    // CSLAM_SCAN_RESERVE_CUS=n leaves n CUs to kernels of other streams (the scan's blocks fill a
+    // CU each — LDS and registers — so a collective's workgroup that sits on one when the scan
+    // starts pushes a scan block into a second round: tools/shard_step_time.py with
+    // CSLAM_LOOPBACK_HOG)
+    const char* reserve_s = getenv("CSLAM_SCAN_RESERVE_CUS");   // read per launch: A/B runs in one process
+    const int reserve_env = reserve_s ? atoi(reserve_s) : 0;
+    const int cus_eff = reserve_env > 0 && reserve_env < p->cus ? p->cus - reserve_env : p->cus;
+    const char* unit_s = getenv("CSLAM_SCAN_PANEL_UNIT");   // 16 = split in whole strips (A/B runs)
+    const int unit = unit_s && atoi(unit_s) == 16 ? 16 : 1;
+    const int64_t nw = (int64_t)cus_eff * NW;
     int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
     if (ppw < 1) ppw = 1;
     int64_t n_panels = nw * ppw;
     const int64_t strips = (p->vn + 15) / 16;
     if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
-    if (best && cand_stride < n_panels) return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
+    // One panel per wave: every wave walks S = ceil(strips / waves) stage rounds per slice whether
+    // its last strip holds 16 rows or 2, so use just enough waves to fill S strips each
+    // (100k rows: 893 waves x 112 rows on 224 CUs instead of 1024 x 97.7 on 256 — 0.2557 ->
+    // 0.2536 ms per step in alternating runs, tools/reserve_ab.py; the scan is HBM-bound and
+    // the idle CUs are free for a collective's kernels).  Splitting in whole strips over ALL
+    // waves (6 or 7 strips each) is slower: 0.2700 ms (profiles/r02_scan_partition_ab.txt).
+    if (ppw == 1 && n_panels == nw && reserve_env == 0 && unit == 1) {
+        const int64_t s_per_wave = (strips + nw - 1) / nw;
+        const int64_t waves = (strips + s_per_wave - 1) / s_per_wave;
+        // only when that idles less than 15 % of the waves: 8192-d x 50k rows would drop to 782
+        // waves (4 full strips each) and runs 7 % SLOWER that way (0.2964 vs 0.2766 ms)
+        if (waves * 100 >= nw * 85) n_panels = waves;
+    }
+    if (best && cand_stride < (n_panels + ppw - 1) / ppw)   // one composite per query and WAVE
+        return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
     const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
     // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
     const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
+
     if (cand_c == nullptr || split < 0) {
         split = INT64_MAX;  // one window
         cand_c = nullptr;
@@ -1836,7 +1867,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
                            lds, st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride,    \
                            q_rows, m, dots, dots_stride, (int)n_panels, (int)ppw,                 \
                            p->inv_norm + p->v0, (uint32_t)p->v0, cand, cand_stride, rnq_out,      \
-                           split, cand_c);                                                        \
+                           split, cand_c, unit);                                                  \
     } while (0)
 #define CSLAM_DMA_LAUNCH_KW(AUX, BEST)                   \
     do {                                                 \
