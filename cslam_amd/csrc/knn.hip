@@ -753,13 +753,13 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       const float* __restrict__ Q, int64_t q_stride,
                                                       int q_rows, int m_valid,
                                                       float* __restrict__ dots,
-                                                      int64_t dots_stride, int n_panels, int ppw,
+                                                      int64_t dots_stride, int n_waves,
                                                       const float* __restrict__ rnx, uint32_t row0,
                                                       uint64_t* __restrict__ cand,
                                                       int64_t cand_stride,
                                                       float* __restrict__ rnq_out,
                                                       int64_t split, uint64_t* __restrict__ cand_c,
-                                                      int unit) {
+                                                      int even) {
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
     static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
@@ -773,21 +773,20 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     const int w = blockIdx.x * NW + wave;
     char* ring = dma_lds + wave * NST * kStage;
     const int nkc = dp / KW;
-    const int p_begin = w * ppw;
-    int p_end = p_begin + ppw;
-    if (p_end > n_panels) p_end = n_panels;
-    if (p_begin >= p_end) return;
-
-    // panel p = rows [p q + min(p, rem), ...): n = q n_panels + rem, the first rem panels one row
-    // longer.  (floor(p n / n_panels) costs two 64-bit divisions, inlined at every one of the
-    // unrolled sites that advance the issue cursor: a third of the kernel's code.)
-    // With unit = 16 the same split is made in whole 16-row strips (the last panel ends at n):
-    // no panel carries a nearly empty strip through all its slices.
-    const int64_t n_units = (n + unit - 1) / unit;
-    const int rows_q = (int)(n_units / n_panels), rows_rem = (int)(n_units - (int64_t)rows_q * n_panels);
+    if (w >= n_waves) return;
+    // wave w owns the rows [wlo, whi) of an even split of the window over the waves and walks
+    // them in p_end panels of <= 128 rows (8 strips)
+    const int64_t wq = n / n_waves, wrem = n - wq * n_waves;
+    const int64_t wlo = (int64_t)w * wq + (w < wrem ? w : wrem);
+    const int64_t whi = wlo + wq + (w < wrem ? 1 : 0);
+    const int p_begin = 0;
+    const int p_end = (int)((whi - wlo + 16 * NS - 1) / (16 * NS));
+    if (p_end == 0) return;
+    // even = 1 (default): p_end equal panels; 0: panels of 128 rows, the remainder last
+    const int pq = (int)((whi - wlo) / p_end), prem = (int)((whi - wlo) - (int64_t)pq * p_end);
     auto panel_lo = [&](int p) {
-        const int64_t v = ((int64_t)p * rows_q + (p < rows_rem ? p : rows_rem)) * unit;
-        return v < n ? v : n;
+        const int64_t v = even ? wlo + (int64_t)p * pq + (p < prem ? p : prem) : wlo + (int64_t)p * (16 * NS);
+        return v < whi ? v : whi;
     };
     auto panel = [&](DmaCursor& c, int p) {
         c.p = p;
@@ -1819,30 +1818,31 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     const char* reserve_s = getenv("CSLAM_SCAN_RESERVE_CUS");   // read per launch: A/B runs in one process
     const int reserve_env = reserve_s ? atoi(reserve_s) : 0;
     const int cus_eff = reserve_env > 0 && reserve_env < p->cus ? p->cus - reserve_env : p->cus;
-    const char* unit_s = getenv("CSLAM_SCAN_PANEL_UNIT");   // 16 = split in whole strips (A/B runs)
-    const int unit = unit_s && atoi(unit_s) == 16 ? 16 : 1;
     const int64_t nw = (int64_t)cus_eff * NW;
-    int64_t ppw = (p->vn + nw * 16 * NS - 1) / (nw * 16 * NS);
-    if (ppw < 1) ppw = 1;
-    int64_t n_panels = nw * ppw;
     const int64_t strips = (p->vn + 15) / 16;
-    if (n_panels > strips) n_panels = strips;  // small pools: one full strip per panel
-    // One panel per wave: every wave walks S = ceil(strips / waves) stage rounds per slice whether
-    // its last strip holds 16 rows or 2, so use just enough waves to fill S strips each
-    // (100k rows: 893 waves x 112 rows on 224 CUs instead of 1024 x 97.7 on 256 — 0.2557 ->
-    // 0.2536 ms per step in alternating runs, tools/reserve_ab.py; the scan is HBM-bound and
-    // the idle CUs are free for a collective's kernels).  Splitting in whole strips over ALL
-    // waves (6 or 7 strips each) is slower: 0.2700 ms (profiles/r02_scan_partition_ab.txt).
-    if (ppw == 1 && n_panels == nw && reserve_env == 0 && unit == 1) {
+    int64_t n_waves = nw < strips ? nw : strips;   // small pools: one full strip per wave
+    // One panel per wave (<= 128 rows each): every wave walks S = ceil(strips / waves) stage rounds
+    // per slice whether its last strip holds 16 rows or 2, so use just enough waves to fill S
+    // strips each (100k rows: 893 waves x 112 rows on 224 CUs instead of 1024 x 97.7 on 256 —
+    // 0.2553 -> 0.2534 ms per step in alternating runs, tools/reserve_ab.py; the scan is
+    // HBM-bound and the idle CUs are free for a collective's kernels).  Only when that idles less
+    // than 15 % of the waves: 8192-d x 50k rows would drop to 782 waves (4 full strips each) and
+    // runs 7 % SLOWER that way (0.2964 vs 0.2766 ms).  Splitting in whole strips over ALL waves
+    // (6 or 7 strips each) is slower too: 0.2700 ms (profiles/r02_scan_partition_ab.txt).
+    if (n_waves == nw && strips <= nw * NS && reserve_env == 0) {
         const int64_t s_per_wave = (strips + nw - 1) / nw;
         const int64_t waves = (strips + s_per_wave - 1) / s_per_wave;
-        // only when that idles less than 15 % of the waves: 8192-d x 50k rows would drop to 782
-        // waves (4 full strips each) and runs 7 % SLOWER that way (0.2964 vs 0.2766 ms)
-        if (waves * 100 >= nw * 85) n_panels = waves;
+        if (waves * 100 >= nw * 85) n_waves = waves;
     }
-    if (best && cand_stride < (n_panels + ppw - 1) / ppw)   // one composite per query and WAVE
+    if (best && cand_stride < n_waves)   // one composite per query and wave
         return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
-    const unsigned blocks = (unsigned)((n_panels + ppw * NW - 1) / (ppw * NW));
+    const unsigned blocks = (unsigned)((n_waves + NW - 1) / NW);
+    // a wave's rows in equal panels (default) or in panels of 128 rows and a remainder
+    // (CSLAM_SCAN_EVEN_PANELS=0; read per launch for A/B runs): fewer stage rounds (390 rows: 8 + 8
+    // + 8 + 1 instead of 4 x 7) but a remainder panel pays the whole per-panel cost — equal panels
+    // win or tie from 256-d to 2048-d (1024-d 0.2597 vs 0.2633 ms), lose 2 % at 128-d
+    const char* even_s = getenv("CSLAM_SCAN_EVEN_PANELS");
+    const int even = even_s && atoi(even_s) == 0 ? 0 : 1;
     // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
     const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
 
@@ -1865,9 +1865,9 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
         }                                                                                         \
         hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST, KW>), dim3(blocks), dim3(NW * 64), \
                            lds, st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride,    \
-                           q_rows, m, dots, dots_stride, (int)n_panels, (int)ppw,                 \
+                           q_rows, m, dots, dots_stride, (int)n_waves,                            \
                            p->inv_norm + p->v0, (uint32_t)p->v0, cand, cand_stride, rnq_out,      \
-                           split, cand_c, unit);                                                  \
+                           split, cand_c, even);                                                  \
     } while (0)
 #define CSLAM_DMA_LAUNCH_KW(AUX, BEST)                   \
     do {                                                 \
@@ -1896,7 +1896,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
 #undef CSLAM_DMA_LAUNCH
     CSLAM_HIP_TRY(hipGetLastError());
     // BEST: candidates per query = waves that hold panels
-    *n_panels_out = best ? (n_panels + ppw - 1) / ppw : n_panels;
+    *n_panels_out = n_waves;
     return CSLAM_OK;
 }
 

@@ -1,5 +1,5 @@
 """How many CUs does the HBM-bound scan need, and should panels be whole strips?
-CSLAM_SCAN_PANEL_UNIT (16 = whole 16-row strips, 1 = rows) and CSLAM_SCAN_RESERVE_CUS A/B in one
+CSLAM_SCAN_EVEN_PANELS (1 = a wave's rows in equal panels, 0 = panels of 128 rows and a remainder) and CSLAM_SCAN_RESERVE_CUS A/B in one
 process (the knobs are read at every launch): 16 best-match queries over 100k x 4096, alternating settings."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = 1_638_400_000 // (D * 4)
-settings = sys.argv[2:] or ["16:0", "1:0", "16:16", "1:16", "16:32", "1:32"]   # panel unit : reserved CUs
+settings = sys.argv[2:] or ["0:0", "1:0", "0:16", "1:16"]   # panel unit : reserved CUs
 X = torch.rand((n, D), device=dev, generator=g)
 pool = NearestNeighborsMatching(dim=D, capacity_hint=n)
 pool.add_items_device(X.data_ptr(), n, D, items=None, stream=st)
@@ -29,7 +29,7 @@ best = {s: 1e9 for s in settings}
 R = 6
 for rnd in range(R):
     for s in settings:
-        os.environ["CSLAM_SCAN_PANEL_UNIT"], os.environ["CSLAM_SCAN_RESERVE_CUS"] = s.split(":")
+        os.environ["CSLAM_SCAN_EVEN_PANELS"], os.environ["CSLAM_SCAN_RESERVE_CUS"] = s.split(":")
         for _ in range(30): run()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(100): run()
@@ -39,4 +39,4 @@ for rnd in range(R):
         assert res == ref
         avg[s] += dt / R; best[s] = min(best[s], dt)
 for s in settings:
-    print(f"D={D} panel unit:reserved CUs {s:>6s}: best {best[s]*1e3:.4f} ms avg {avg[s]*1e3:.4f} ms  {n*D*4/avg[s]/1e12:.2f} TB/s", flush=True)
+    print(f"D={D} even panels:reserved CUs {s:>6s}: best {best[s]*1e3:.4f} ms avg {avg[s]*1e3:.4f} ms  {n*D*4/avg[s]/1e12:.2f} TB/s", flush=True)
