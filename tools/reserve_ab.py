@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
 st = torch.cuda.current_stream().cuda_stream
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-n = 1_638_400_000 // (D * 4)
+n = int(os.environ.get("AB_ROWS", 1_638_400_000 // (D * 4)))
 settings = sys.argv[2:] or ["0:0", "1:0", "0:16", "1:16"]   # panel unit : reserved CUs
 X = torch.rand((n, D), device=dev, generator=g)
 pool = NearestNeighborsMatching(dim=D, capacity_hint=n)
