@@ -657,13 +657,14 @@ __global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ 
 //   Numerics: per (row, query) the MFMA chain visits k in the canonical order, accumulators
 //   are carried per strip across the two slices of a 512-float chunk and folded exactly like
 //   k_scan -> identical bits (tests/test_knn_gpu.py).
-//   Requires dp % 256 == 0 (the host falls back to k_scan otherwise).
+//   Requires dp % 64 == 0 (slice width KW = 256 / 128 / 64, see DmaGeom below; the pool pads rows of
+//   more than 16 floats to a multiple of 64, shorter ones take k_scan).
 // ---------------------------------------------------------------------------------------------
 constexpr int kDmaPieceB = 1024 + 32;          // bytes per row piece in LDS
 constexpr int kDmaStageB = 16 * kDmaPieceB;    // 16 rows x 256 floats
 // rows from which the DMA scan is the default.  It wins at every size (16-query search_best, us:
 // 64 rows x 4096-d 47 vs 175 for the register ring, 32k rows 103 vs 281; 64 rows x 512-d 16 vs 33,
-// tools/small_n_sweep.py) — the ring kernel stays for dims that are not a multiple of 256.
+// tools/small_n_sweep.py) — the ring kernel stays for descriptors of <= 16 floats and for 17-64 queries.
 constexpr int64_t kDmaMinRows = 1;
 
 __device__ inline void wait_vm_dyn(int n) {

@@ -353,7 +353,7 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
     (4000, 576, 11, 1),       # nine slices: 512 + 64
 ])
 def test_dma_scan_matches_oracle(gpu, n, d, m, k):
-    """k_scan_dma (the default dots kernel from 16384 rows when dim % 256 == 0) against the C
+    """k_scan_dma (the default scan for <= 16 queries; slice width 256 / 128 / 64 floats) against the C
     oracle, bit for bit, on shapes that cover its panel / strip / slice edge cases."""
     rs = np.random.RandomState(n + d)
     X = (rs.rand(n, d).astype(np.float32) - 0.3)
