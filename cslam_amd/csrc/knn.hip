@@ -979,22 +979,51 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
             if (rnq_out != nullptr && w == 0 && g == 0 && r < m_valid) rnq_out[r] = rnq;
         }
         if (BEST) {
+            // Branch-free per value (rows past the panel's end become the empty composite 0), row
+            // numbers relative to the panel in 32 bits, the four norms of a row group fetched
+            // before they are used, and the two-window bookkeeping only in panels the split
+            // row falls into or lies in front of (wave-uniform): the epilogue is a tenth of a
+            // panel's time at 64-d.
             uint64_t best = 0, best_c = 0;
             const bool two = split < hi;  // wave-uniform: rows >= split in this panel
+            const int prow = (int)(hi - lo);
+            const uint32_t rbase = row0 + (uint32_t)lo;
+            const int srel = split > lo ? (int)((split < hi ? split : hi) - lo) : 0;  // first panel row of window c
+            if (!two) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s < ns) {
-                    const int64_t r0 = lo + 16 * s + 4 * g;
+                for (int s = 0; s < NS; ++s) {
+                    if (s < ns) {
+                        float rn[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float rn = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
-                        if (r0 + e < hi) {
-                            const float sim = (tot[s][e] * rn) * rnq;
-                            const uint64_t c = make_comp(sim, row0 + (uint32_t)(r0 + e));
-                            if (two && r0 + e >= split)
-                                best_c = c > best_c ? c : best_c;
-                            else
-                                best = c > best ? c : best;
+                        for (int e = 0; e < 4; ++e)
+                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rel = 16 * s + 4 * g + e;
+                            const float sim = (tot[s][e] * rn[e]) * rnq;
+                            uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+                            c = rel < prow ? c : 0;
+                            best = c > best ? c : best;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s < ns) {
+                        float rn[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int rel = 16 * s + 4 * g + e;
+                            const float sim = (tot[s][e] * rn[e]) * rnq;
+                            uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+                            c = rel < prow ? c : 0;
+                            const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
+                            best = ca > best ? ca : best;
+                            best_c = cc > best_c ? cc : best_c;
                         }
                     }
                 }
