@@ -73,7 +73,10 @@ int cslam_pool_device(const cslam_pool_t* pool);       /* HIP device the pool li
 int cslam_pool_read_rows(const cslam_pool_t* pool, int64_t first, int64_t n, float* out);
 /* cached 1/max(||row||,1e-8) for rows [first, first+n) → host. */
 int cslam_pool_read_inv_norms(const cslam_pool_t* pool, int64_t first, int64_t n, float* out);
-/* device address of the row storage and its stride in floats (for zero-copy consumers). */
+/* device address of the row storage and its stride in floats (for zero-copy consumers).
+ * The stride is NOT the dimension in general: rows are zero-padded to a multiple of 64 floats and,
+ * when that makes the stride a multiple of 4 KiB, followed by another 128 floats that are never
+ * read — always index rows with the stride returned here. */
 int cslam_pool_device_view(const cslam_pool_t* pool, const float** rows_dev, int64_t* row_stride);
 
 /* search (nns_matching.py:44-63) for n_queries queries at once.
