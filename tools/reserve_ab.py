@@ -29,7 +29,7 @@ best = {s: 1e9 for s in settings}
 R = 6
 for rnd in range(R):
     for s in settings:
-        os.environ["CSLAM_SCAN_EVEN_PANELS"], os.environ["CSLAM_SCAN_RESERVE_CUS"] = s.split(":")
+        os.environ[os.environ.get("AB_KNOB", "CSLAM_SCAN_EVEN_PANELS")], os.environ["CSLAM_SCAN_RESERVE_CUS"] = s.split(":")
         for _ in range(30): run()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(100): run()
@@ -39,4 +39,4 @@ for rnd in range(R):
         assert res == ref
         avg[s] += dt / R; best[s] = min(best[s], dt)
 for s in settings:
-    print(f"D={D} even panels:reserved CUs {s:>6s}: best {best[s]*1e3:.4f} ms avg {avg[s]*1e3:.4f} ms  {n*D*4/avg[s]/1e12:.2f} TB/s", flush=True)
+    print(f"D={D} rows={n} {os.environ.get('AB_KNOB', 'CSLAM_SCAN_EVEN_PANELS')}:reserved CUs {s:>6s}: best {best[s]*1e3:.4f} ms avg {avg[s]*1e3:.4f} ms  {n*D*4/avg[s]/1e12:.2f} TB/s", flush=True)
