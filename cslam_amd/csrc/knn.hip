@@ -1834,6 +1834,25 @@ bool ks_scan_applies(const cslam_pool* p, int m) {
     return strips <= p->cus && nchunks >= 4 && nchunks <= kKsMaxChunks;
 }
 
+// measurement knobs: read once — or at every launch when CSLAM_KNOBS_LIVE is set, so that a tool can
+// alternate settings inside one process (tools/reserve_ab.py; boxes and processes differ by
+// more than the effects in question)
+struct Knob {
+    const char* name;
+    int def;
+    int value = 0;
+    bool init = false;
+};
+int knob(Knob& k) {
+    static const bool live = getenv("CSLAM_KNOBS_LIVE") != nullptr;
+    if (live || !k.init) {
+        const char* s = getenv(k.name);
+        k.value = s ? atoi(s) : k.def;
+        k.init = true;
+    }
+    return k.value;
+}
+
 // k_scan_dma over the row window [v0, v0+vn): either raw dots (best = false) or one (similarity,
 // row) composite per query and panel (best = true, *n_panels_out candidates per query)
 int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
@@ -1845,8 +1864,8 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     // CU each — LDS and registers — so a collective's workgroup that sits on one when the scan
     // starts pushes a scan block into a second round: tools/shard_step_time.py with
     // CSLAM_LOOPBACK_HOG)
-    const char* reserve_s = getenv("CSLAM_SCAN_RESERVE_CUS");   // read per launch: A/B runs in one process
-    const int reserve_env = reserve_s ? atoi(reserve_s) : 0;
+    static Knob k_reserve{"CSLAM_SCAN_RESERVE_CUS", 0}, k_even{"CSLAM_SCAN_EVEN_PANELS", 1};
+    const int reserve_env = knob(k_reserve);
     const int cus_eff = reserve_env > 0 && reserve_env < p->cus ? p->cus - reserve_env : p->cus;
     const int64_t nw = (int64_t)cus_eff * NW;
     const int64_t strips = (p->vn + 15) / 16;
@@ -1868,11 +1887,10 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
         return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
     const unsigned blocks = (unsigned)((n_waves + NW - 1) / NW);
     // a wave's rows in equal panels (default) or in panels of 128 rows and a remainder
-    // (CSLAM_SCAN_EVEN_PANELS=0; read per launch for A/B runs): fewer stage rounds (390 rows: 8 + 8
+    // (CSLAM_SCAN_EVEN_PANELS=0): fewer stage rounds (390 rows: 8 + 8
     // + 8 + 1 instead of 4 x 7) but a remainder panel pays the whole per-panel cost — equal panels
     // win or tie from 256-d to 2048-d (1024-d 0.2597 vs 0.2633 ms), lose 2 % at 128-d
-    const char* even_s = getenv("CSLAM_SCAN_EVEN_PANELS");
-    const int even = even_s && atoi(even_s) == 0 ? 0 : 1;
+    const int even = knob(k_even) == 0 ? 0 : 1;
     // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
     const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
 

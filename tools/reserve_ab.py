@@ -1,7 +1,8 @@
 """How many CUs does the HBM-bound scan need, and should panels be whole strips?
 CSLAM_SCAN_EVEN_PANELS (1 = a wave's rows in equal panels, 0 = panels of 128 rows and a remainder) and CSLAM_SCAN_RESERVE_CUS A/B in one
-process (the knobs are read at every launch): 16 best-match queries over 100k x 4096, alternating settings."""
+process (CSLAM_KNOBS_LIVE: the library re-reads the knobs at every launch): 16 best-match queries over 100k x 4096, alternating settings."""
 import ctypes, os, sys, time
+os.environ["CSLAM_KNOBS_LIVE"] = "1"   # the library re-reads its measurement knobs at every launch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cslam_amd import _lib
