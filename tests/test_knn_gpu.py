@@ -528,3 +528,34 @@ def test_narrow_gemm_tiles_for_129_to_192_queries(gpu):
     np.testing.assert_array_equal(rows, o_idx)
     assert sims.tobytes() == o_sim.tobytes()
     pool.close()
+
+
+@pytest.mark.parametrize("dim,stride", [(4096, 4096 + 128), (1024, 1024 + 128), (512, 512), (128, 128),
+                                        (100, 128), (33, 64), (10, 16), (3000, 3008)])
+def test_row_layout_padding_is_invisible_to_callers(gpu, dim, stride):
+    """Rows are stored zero-padded to a multiple of 64 floats (16 for tiny descriptors) and 512 B
+    further apart when the stride would be a multiple of 4 KiB: the device view
+    reports that stride, `.data` still reads back the dense rows, the zero padding is really zero,
+    and a pool grown across a reallocation keeps every row."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    from cslam_amd import _lib
+    rs = np.random.RandomState(dim)
+    X = rs.rand(1500, dim).astype(np.float32)
+    m = _pool(gpu, X[:900], dim=dim)              # capacity 1000 ...
+    m.add_items(X[900:], list(range(900, 1500)))  # ... grown to 2000
+    rows_dev, row_stride = ctypes.c_void_p(), ctypes.c_int64()
+    _lib.check(gpu.cslam_pool_device_view(m.handle, ctypes.byref(rows_dev), ctypes.byref(row_stride)))
+    assert row_stride.value == stride
+    np.testing.assert_array_equal(m.data.cpu().numpy()[:1500], X)
+    dp = (dim + 63) // 64 * 64 if dim > 16 else 16
+    if dp > dim:                                  # the padding behind row 1234 is zero
+        pad = torch.empty(dp - dim, dtype=torch.float32, device="cuda")
+        _lib.check(gpu.cslam_device_copy(ctypes.c_void_p(pad.data_ptr()),
+                                         ctypes.c_void_p(rows_dev.value + (1234 * stride + dim) * 4),
+                                         (dp - dim) * 4, 2, None, 1))
+        assert float(pad.abs().max()) == 0.0
+    q = X[[7, 1234]]
+    rows, sims = m.search_batch(q, 1)
+    np.testing.assert_array_equal(rows[:, 0], [7, 1234])
+    m.close()
