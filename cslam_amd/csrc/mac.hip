@@ -656,18 +656,19 @@ __device__ inline bool rqi_smallest(const double (&C)[3][3], double& theta, doub
 #pragma unroll
     for (int i = 0; i < K; ++i) res += fabs(cv[i] - th * v[i]);
     if (!(res <= 1e-12 * scale)) return false;
+    // inertia of C - sh I by Sylvester's criterion: the leading principal minors instead of the
+    // LDL^T pivots — the same signs without three dependent fp64 divisions on the critical path
     const double sh = th - 1e-9 * scale;
-    const double d0 = C[0][0] - sh;
-    if (!(d0 > 0.0)) return false;
+    const double m00 = C[0][0] - sh;
+    if (!(m00 > 0.0)) return false;
     if (K >= 2) {
-        const double l10 = C[1][0] / d0;
-        const double d1 = (C[1][1] - sh) - l10 * C[1][0];
-        if (!(d1 > 0.0)) return false;
+        const double m11 = C[1][1] - sh, m01 = C[1][0];
+        const double minor2 = m00 * m11 - m01 * m01;
+        if (!(minor2 > 0.0)) return false;
         if (K == 3) {
-            const double l20 = C[2][0] / d0;
-            const double m21 = C[2][1] - l20 * C[1][0];
-            const double d2 = (C[2][2] - sh) - l20 * C[2][0] - (m21 / d1) * m21;
-            if (!(d2 > 0.0)) return false;
+            const double m22 = C[2][2] - sh, m02 = C[2][0], m12 = C[2][1];
+            const double det = m22 * minor2 - m12 * (m00 * m12 - m01 * m02) + m02 * (m01 * m12 - m11 * m02);
+            if (!(det > 0.0)) return false;
         }
     }
     theta = th;
