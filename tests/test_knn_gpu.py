@@ -559,3 +559,32 @@ def test_row_layout_padding_is_invisible_to_callers(gpu, dim, stride):
     rows, sims = m.search_batch(q, 1)
     np.testing.assert_array_equal(rows[:, 0], [7, 1234])
     m.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (4097, 100, 16, 10),      # 112-float rows: register-ring scan, two select parts
+    (3000, 1000, 7, 1),       # 1008-float rows, best match through dots + select
+    (2500, 4096, 16, 1),      # dense 16-KiB rows (no stride pad): the LDS-DMA scan on the round-1 layout
+    (900, 48, 5, 3),
+])
+def test_round1_row_layout_knobs_still_bit_exact(gpu, monkeypatch, n, d, m, k):
+    """CSLAM_DIM_ALIGN=16 / CSLAM_ROW_PAD=0 (read at pool creation) keep the tight round-1 layout:
+    lengths that are no multiple of 64 floats then take the register-ring scan.  Same bits."""
+    import ctypes
+    from cslam_amd import _lib
+    monkeypatch.setenv("CSLAM_DIM_ALIGN", "16")
+    monkeypatch.setenv("CSLAM_ROW_PAD", "0")
+    rs = np.random.RandomState(n + d + 1)
+    X = (rs.rand(n, d).astype(np.float32) - 0.4)
+    Q = rs.rand(m, d).astype(np.float32)
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows_dev, row_stride = ctypes.c_void_p(), ctypes.c_int64()
+    _lib.check(gpu.cslam_pool_device_view(mt.handle, ctypes.byref(rows_dev), ctypes.byref(row_stride)))
+    assert row_stride.value == (d + 15) // 16 * 16
+    rows, sims = mt.search_batch(Q, k)
+    kernel = gpu.cslam_pool_scan_kernel(mt.handle).decode()
+    assert kernel.startswith("k_scan<" if row_stride.value % 64 else "k_scan_dma"), kernel
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, k)
+    np.testing.assert_array_equal(rows, o_idx)
+    assert sims.tobytes() == o_sim.tobytes()
+    mt.close()
