@@ -323,321 +323,6 @@ __global__ __launch_bounds__(256) void k_scan(const float* __restrict__ X, int64
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan_lds<S,NW>: the HBM-bound scan (<= 16 queries) with LDS-staged query tiles.
-//   Block = NW waves that walk k in lockstep, one 512-float stage (= one fold chunk) at a time.
-//   The stage's query tile [16 cols][512 floats] is staged ONCE per block into LDS (double
-//   buffered, prefetched one stage ahead through registers) and shared by the NW waves: the
-//   L2 query stream drops to 1/(NW*S) of the X stream, so waves can be many (16 per CU) and
-//   narrow (S = 1..2 strips) — the shape that streams best (profiles/r01_bw_probe2.txt).
-//   Each wave: own byte-balanced row range, bursts of 8 k-blocks x S strips straight from HBM
-//   to VGPRs (predicated, no clamped duplicates), B fragment by ds_read_b128 (column pitch
-//   516 floats → conflict free), same MFMA order and chunk folds as k_scan → identical bits.
-//   One barrier per stage; no divisibility constraint on the dimension.
-// ---------------------------------------------------------------------------------------------
-constexpr int kStageKb = kChunkKb;                 // 32 k-blocks = 512 floats per stage
-constexpr int kQPitch = kStageKb * 16 + 4;         // floats per query column in LDS
-
-template <int S, int NW>
-__global__ __launch_bounds__(NW * 64) void k_scan_lds(const float* __restrict__ X, int64_t xs,
-                                                      int64_t n, int dp,
-                                                      const float* __restrict__ Q, int m_valid,
-                                                      float* __restrict__ dots,
-                                                      int64_t dots_stride, int64_t n_waves,
-                                                      int ngroups) {
-    __shared__ __attribute__((aligned(16))) float qs[2][16 * kQPitch];
-    constexpr int NT = NW * 64;
-    constexpr int NQ = (16 * kStageKb * 4) / NT;   // float4 per thread per stage
-    constexpr int UB = 8;                          // k-blocks per burst
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int r = lane & 15;
-    const int g = lane >> 4;
-    const int64_t w = (int64_t)blockIdx.x * NW + wave;
-    const int64_t lo = w < n_waves ? (w * n) / n_waves : 0;
-    const int64_t hi = w < n_waves ? ((w + 1) * n) / n_waves : 0;
-    const int nkb = dp >> 4;
-    const int nstage = (nkb + kStageKb - 1) / kStageKb;
-    const int total = ngroups * nstage;
-
-    f32x4 qreg[NQ];
-    auto load_q = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int f = tid + i * NT;            // float4 index inside the stage tile
-            const int c = f / (kStageKb * 4);
-            const int j = f % (kStageKb * 4);
-            const int k = st * (kStageKb * 16) + 4 * j;
-            qreg[i] = (k < dp) ? *reinterpret_cast<const f32x4*>(Q + (int64_t)c * dp + k)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto store_q = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int f = tid + i * NT;
-            const int c = f / (kStageKb * 4);
-            const int j = f % (kStageKb * 4);
-            *reinterpret_cast<f32x4*>(&qs[buf][c * kQPitch + 4 * j]) = qreg[i];
-        }
-    };
-    load_q(0);
-    store_q(0);
-    __syncthreads();
-
-    int gi = 0;
-    for (int grp = 0; grp < ngroups; ++grp) {
-        const f32x4* xp[S];
-        bool valid[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int64_t row = lo + (int64_t)grp * (16 * S) + 16 * s + r;
-            valid[s] = row < hi;
-            xp[s] = reinterpret_cast<const f32x4*>(X + (valid[s] ? row : 0) * xs + 4 * g);
-        }
-        f32x4 tot[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int st = 0; st < nstage; ++st, ++gi) {
-            const int buf = gi & 1;
-            const bool has_next = gi + 1 < total;
-            if (has_next) load_q(st + 1 == nstage ? 0 : st + 1);
-            f32x4 acc[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int kb_lo = st * kStageKb;
-            const int kb_hi = min(nkb, kb_lo + kStageKb);
-            const float* qrow = &qs[buf][r * kQPitch + 4 * g];
-            for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += UB) {
-                f32x4 a[UB][S];
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        a[u][s] = (valid[s] && kb0 + u < kb_hi) ? xp[s][(kb0 + u) * 4]
-                                                                : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    if (kb0 + u < kb_hi) {
-                        const f32x4 b =
-                            *reinterpret_cast<const f32x4*>(qrow + (kb0 + u - kb_lo) * 16);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int s = 0; s < S; ++s)
-                                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s][j], b[j],
-                                                                              acc[s], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < S; ++s) tot[s] = tot[s] + acc[s];
-            if (has_next) store_q(buf ^ 1);
-            __syncthreads();
-        }
-        if (r < m_valid) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int64_t r0 = lo + (int64_t)grp * (16 * S) + 16 * s + 4 * g;
-                float* out = dots + (int64_t)r * dots_stride + r0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (r0 + e < hi) out[e] = tot[s][e];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_scan_pc<S,NWV>: producer/consumer scan (<= 16 queries).
-//   Measured: whatever a CU pulls through its L1-miss path — HBM rows or L2-resident queries —
-//   shares one budget of ~10.6 B/clk (≈6.5 TB/s chip-wide): with the queries loaded from L2 the
-//   X stream is capped at 6.5/(1+1/S) TB/s (S = 8 → 5.3 measured).  Here the queries never use
-//   that path: wave 0 of each block (one block per CU) streams the staged query block into a
-//   deep LDS ring, stage by stage (256 floats x 16 columns), and the other NWV-1 waves read
-//   their B fragments from LDS.  No barriers: the producer publishes `ready` (stages filled),
-//   every consumer publishes its own progress; the producer refills a slot once all consumers
-//   are past it.  Consumers drift up to kPcRing-1 stages apart, so one wave's slow HBM burst
-//   does not stall the others (the per-stage barrier of k_scan_lds did exactly that).
-//   X path, MFMA order and chunk folds are those of k_scan → identical bits.
-//   Every spin is bounded: on timeout the wave sets *fault and leaves (no hung GPU).
-// ---------------------------------------------------------------------------------------------
-constexpr int kPcStageKb = 16;                       // k-blocks per query stage (256 floats)
-constexpr int kPcPitch = kPcStageKb * 16 + 4;        // floats per query column per stage
-constexpr int kPcRing = 8;                           // stages in the LDS ring
-constexpr int kPcSpinMax = 1 << 22;
-
-template <int S, int NWV>
-__global__ __launch_bounds__(NWV * 64) void k_scan_pc(const float* __restrict__ X, int64_t xs,
-                                                      int64_t n, int dp,
-                                                      const float* __restrict__ Q, int m_valid,
-                                                      float* __restrict__ dots,
-                                                      int64_t dots_stride, int64_t n_cons,
-                                                      int ngroups, int* __restrict__ fault) {
-    extern __shared__ __attribute__((aligned(16))) float pc_lds[];
-    float* qs = pc_lds;                                           // [kPcRing][16 * kPcPitch]
-    int* ready = reinterpret_cast<int*>(pc_lds + kPcRing * 16 * kPcPitch);   // stages published
-    int* progress = ready + 1;                                    // [NWV] stages consumed
-    constexpr int NC = NWV - 1;
-    constexpr int UB = 8;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nkb = dp >> 4;
-    const int nstage = (nkb + kPcStageKb - 1) / kPcStageKb;
-    const int total = ngroups * nstage;
-
-    if (tid == 0) *ready = 0;
-    if (tid < NWV) progress[tid] = 0;
-    __syncthreads();
-
-    if (wave == 0) {
-        // ---------------- producer: query stages → LDS ring ----------------
-        for (int j = 0; j < total; ++j) {
-            const int st = j % nstage;
-            f32x4 qreg[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int f = lane + i * 64;                 // float4 index in the stage tile
-                const int c = f / (kPcStageKb * 4);
-                const int jj = f % (kPcStageKb * 4);
-                const int k = st * (kPcStageKb * 16) + 4 * jj;
-                qreg[i] = (k < dp) ? *reinterpret_cast<const f32x4*>(Q + (int64_t)c * dp + k)
-                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (j >= kPcRing) {  // slot still in use? wait for the slowest consumer
-                int spins = 0;
-                while (true) {
-                    int mn = 1 << 30;
-                    for (int cw = 1; cw < NWV; ++cw) {
-                        int pv = __hip_atomic_load(&progress[cw], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                        mn = pv < mn ? pv : mn;
-                    }
-                    if (mn >= j - kPcRing + 1) break;
-                    if (++spins > kPcSpinMax) {
-                        if (lane == 0) *fault = 1;
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            float* slot = qs + (j % kPcRing) * (16 * kPcPitch);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int f = lane + i * 64;
-                const int c = f / (kPcStageKb * 4);
-                const int jj = f % (kPcStageKb * 4);
-                *reinterpret_cast<f32x4*>(slot + c * kPcPitch + 4 * jj) = qreg[i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0)
-                __hip_atomic_store(ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        return;
-    }
-
-    // ---------------- consumers ----------------
-    // Two register buffers (one per half stage = 8 k-blocks x S strips), each refilled for the
-    // NEXT stage right after it is consumed: a wave always has a full stage of X in flight,
-    // across stage and group boundaries, and X loads never wait for the query ring.
-    const int r = lane & 15;
-    const int g = lane >> 4;
-    const int64_t w = (int64_t)blockIdx.x * NC + (wave - 1);
-    const int64_t lo = w < n_cons ? (w * n) / n_cons : 0;
-    const int64_t hi = w < n_cons ? ((w + 1) * n) / n_cons : 0;
-
-    f32x4 bufA[UB][S], bufB[UB][S];
-    auto issue = [&](f32x4 (&buf)[UB][S], int grp, int st, int half) {
-        // branch-free (nkb % kPcStageKb == 0 is a launch precondition): rows past the range
-        // and the prefetch past the last group are clamped — duplicates hit L1, never stored
-        const int kb0 = st * kPcStageKb + half * UB;
-        const int gq = grp < ngroups ? grp : ngroups - 1;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            int64_t row = lo + (int64_t)gq * (16 * S) + 16 * s + r;
-            if (row >= hi) row = hi - 1;
-            if (row < 0) row = 0;
-            const f32x4* xp = reinterpret_cast<const f32x4*>(X + row * xs + 4 * g) + kb0 * 4;
-#pragma unroll
-            for (int u = 0; u < UB; ++u) buf[u][s] = xp[u * 4];
-        }
-    };
-    f32x4 tot[S], acc[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    auto compute = [&](const f32x4 (&buf)[UB][S], const float* qrow, int st, int half) {
-        (void)st;
-        f32x4 b[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u)
-            b[u] = *reinterpret_cast<const f32x4*>(qrow + (half * UB + u) * 16);
-#pragma unroll
-        for (int u = 0; u < UB; ++u)
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx)
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(buf[u][s][jx], b[u][jx], acc[s], 0,
-                                                                  0, 0);
-    };
-    issue(bufA, 0, 0, 0);
-    issue(bufB, 0, 0, 1);
-    int j = 0;
-    for (int grp = 0; grp < ngroups; ++grp) {
-        for (int st = 0; st < nstage; ++st, ++j) {
-            const int ngrp = st + 1 < nstage ? grp : grp + 1;
-            const int nst = st + 1 < nstage ? st + 1 : 0;
-            {
-                int spins = 0;
-                while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) {
-                    if (++spins > kPcSpinMax) {
-                        if (lane == 0) *fault = 2;
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            const float* qrow = qs + (j % kPcRing) * (16 * kPcPitch) + r * kPcPitch + 4 * g;
-            compute(bufA, qrow, st, 0);
-            issue(bufA, ngrp, nst, 0);
-            compute(bufB, qrow, st, 1);
-            issue(bufB, ngrp, nst, 1);
-            // chunk fold every kChunkKb k-blocks and at the end of the row
-            if (((st + 1) * kPcStageKb) % kChunkKb == 0 || st + 1 == nstage) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    tot[s] = tot[s] + acc[s];
-                    acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            // this wave is done with stage j (its LDS reads have returned: the MFMAs used them)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0)
-                __hip_atomic_store(&progress[wave], j + 1, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (r < m_valid) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int64_t r0 = lo + (int64_t)grp * (16 * S) + 16 * s + 4 * g;
-                float* out = dots + (int64_t)r * dots_stride + r0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (r0 + e < hi) out[e] = tot[s][e];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) tot[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_scan_dma<NS,NW,NST,AUX>: the HBM-bound scan (<= 16 queries) with X streamed through LDS-DMA.
 //   Why: the MFMA A-operand shape (16 rows x 64 B per load instruction) touches 16 half lines
 //   per instruction and tops out at 5.1-5.3 TB/s in k_scan; a linear 1-KiB-per-instruction
@@ -1714,7 +1399,7 @@ struct cslam_pool {
     float* rows = nullptr;      // [cap][dp]
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
-    DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, fault;
+    DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp;
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
     PinBuf pin_rows;                   // pinned ring of cslam_pool_add's small appends
@@ -1731,6 +1416,12 @@ struct cslam_pool {
     hipEvent_t dev_ev = nullptr;
     hipStream_t dev_stream = nullptr;
     bool dev_pending = false;
+    // ... and the sharded step's append, which runs on the exchange stream while scans of earlier
+    // steps are still marked on the compute stream: an event of its own, so that neither mark
+    // hides the other
+    hipEvent_t app_ev = nullptr;
+    hipStream_t app_stream = nullptr;
+    bool app_pending = false;
 };
 
 namespace {
@@ -1739,6 +1430,15 @@ namespace {
 int order_after_dev(cslam_pool* p, hipStream_t st) {
     if (p->dev_pending && p->dev_stream != st)
         CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->dev_ev, 0));
+    if (p->app_pending && p->app_stream != st) {
+        // the append was issued a whole step ahead of the scan that needs it: normally it is
+        // complete, and then the stream is spared the cross-stream barrier packet (~10 us in
+        // front of a scan, profiles/r02_shard_step_timeline.txt)
+        if (hipEventQuery(p->app_ev) == hipSuccess)
+            p->app_pending = false;
+        else
+            CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->app_ev, 0));
+    }
     return CSLAM_OK;
 }
 // remember that device-API work is in flight on `st`
@@ -1757,6 +1457,11 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     float* nnorm = nullptr;
     CSLAM_HIP_TRY(hipMalloc(&nrows, (size_t)ncap * p->xs * sizeof(float)));
     CSLAM_HIP_TRY(hipMalloc(&nnorm, (size_t)ncap * sizeof(float)));
+    // A growth waits for the whole device, BEFORE the old rows are copied: appends may still be
+    // pending on other streams (cslam_pool_add's pinned-ring kernel on the handle's stream, the
+    // sharded step's append on its exchange stream) and `st` is not ordered behind them; scans
+    // on other streams may still read the old buffers (rare: capacities double)
+    if (p->rows) CSLAM_HIP_TRY(hipDeviceSynchronize());
     if (p->n > 0) {
         CSLAM_HIP_TRY(hipMemcpyAsync(nrows, p->rows, (size_t)p->n * p->xs * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
@@ -1766,9 +1471,7 @@ int pool_grow(cslam_pool* p, int64_t want_rows, hipStream_t st) {
     CSLAM_HIP_TRY(hipMemsetAsync(nrows + p->n * p->xs, 0,
                                  (size_t)(ncap - p->n) * p->xs * sizeof(float), st));
     CSLAM_HIP_TRY(hipMemsetAsync(nnorm + p->n, 0, (size_t)(ncap - p->n) * sizeof(float), st));
-    // scans on other streams (the sharded step appends on its exchange stream) may still read
-    // the old buffers: a growth waits for the whole device (rare: capacities double)
-    CSLAM_HIP_TRY(hipDeviceSynchronize());
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));   // the copies are done before the old buffers go
     if (p->rows) CSLAM_HIP_TRY(hipFree(p->rows));
     if (p->inv_norm) CSLAM_HIP_TRY(hipFree(p->inv_norm));
     p->rows = nrows;
@@ -1811,15 +1514,13 @@ bool prof_take(cslam_pool* p) {
     return (p->prof_tick++ % p->prof_every) == 0;
 }
 
-// does the DMA scan apply to the current row window?  (env: CSLAM_SCAN_KERNEL=ring|lds|pc keeps
-// the older kernels, =dma forces it below its switch-over size)
+// does the DMA scan apply to the current row window?  (env: CSLAM_SCAN_KERNEL=ring keeps the
+// round-1 register-ring kernel for A/B runs)
 bool dma_scan_applies(const cslam_pool* p) {
     static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
     if (p->dp % 64 != 0 || p->vn <= 0) return false;
     if (kern_env && strcmp(kern_env, "dma") == 0) return true;
-    if (kern_env && (strcmp(kern_env, "ring") == 0 || strcmp(kern_env, "lds") == 0 ||
-                     strcmp(kern_env, "pc") == 0))
-        return false;
+    if (kern_env && strcmp(kern_env, "ring") == 0) return false;
     return p->vn >= kDmaMinRows;
 }
 
@@ -1965,12 +1666,6 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
     if (m <= 16) {
-        static const char* kern_env = getenv("CSLAM_SCAN_KERNEL");
-        // default: register-ring kernel (5.3 TB/s); "lds" selects the block-synchronous
-        // LDS-staged variant (4.5-4.9 TB/s measured: the per-stage barrier couples 8 waves'
-        // HBM latencies; kept for A/B runs, profiles/r01_scan_lds_vs_ring.txt)
-        const bool use_lds = kern_env && strcmp(kern_env, "lds") == 0;
-        const bool use_pc = kern_env && strcmp(kern_env, "pc") == 0;
         // X through LDS-DMA (k_scan_dma, 6.0-6.3 TB/s) for pools that are worth it
         const bool use_dma = dma_scan_applies(p);
         // small pool, long descriptors, staged queries: the block-per-strip K-split kernel
@@ -1997,65 +1692,6 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
             // rnq_out set: Qstage are the caller's queries read in place (no staging ran)
             CSLAM_TRY(launch_scan_dma(p, Qstage, rnq_out ? q_stride : p->dp, rnq_out ? m : 16, m, dots,
                                       dots_stride, false, nullptr, 0, &n_panels, st, rnq_out));
-        } else if (use_pc && p->dp % (kPcStageKb * 16) == 0 && p->vn > 0) {
-            p->last_scan_kernel = "k_scan_pc";
-            static const int ps_env = getenv("CSLAM_SCAN_PS") ? atoi(getenv("CSLAM_SCAN_PS")) : 0;
-            static const int pw_env = getenv("CSLAM_SCAN_PW") ? atoi(getenv("CSLAM_SCAN_PW")) : 0;
-            const int PS = ps_env == 1 ? 1 : 2;
-            const int NWV = pw_env == 8 ? 8 : (pw_env == 12 ? 12 : 16);
-            const int NC = NWV - 1;
-            int64_t strips = (p->vn + 15) / 16;
-            int64_t blocks = (strips + NC - 1) / NC;
-            if (blocks > (int64_t)p->cus) blocks = p->cus;
-            if (blocks < 1) blocks = 1;
-            const int64_t nc = blocks * NC < p->vn ? blocks * NC : (p->vn > 0 ? p->vn : 1);
-            const int64_t rows_max = (p->vn + nc - 1) / nc;
-            const int ngroups = (int)((rows_max + 16 * PS - 1) / (16 * PS));
-            const size_t lds = (size_t)kPcRing * 16 * kPcPitch * sizeof(float) + (1 + 16) * sizeof(int);
-            CSLAM_TRY(p->fault.reserve(sizeof(int)));
-            CSLAM_HIP_TRY(hipMemsetAsync(p->fault.p, 0, sizeof(int), st));
-#define CSLAM_PC_LAUNCH(SS, WW)                                                                   \
-    do {                                                                                          \
-        static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
-        if (!attr_set[p->device & 63]) {                                                          \
-            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_pc<SS, WW>,                     \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                              (int)lds));                                         \
-            attr_set[p->device & 63] = true;                                                      \
-        }                                                                                         \
-        hipLaunchKernelGGL((k_scan_pc<SS, WW>), dim3((unsigned)blocks), dim3(WW * 64), lds, st,   \
-                           p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,         \
-                           dots_stride, nc, ngroups, p->fault.as<int>());                         \
-    } while (0)
-            if (PS == 1 && NWV == 16) CSLAM_PC_LAUNCH(1, 16);
-            else if (PS == 1 && NWV == 12) CSLAM_PC_LAUNCH(1, 12);
-            else if (PS == 1) CSLAM_PC_LAUNCH(1, 8);
-            else if (NWV == 16) CSLAM_PC_LAUNCH(2, 16);
-            else if (NWV == 12) CSLAM_PC_LAUNCH(2, 12);
-            else CSLAM_PC_LAUNCH(2, 8);
-#undef CSLAM_PC_LAUNCH
-        } else if (use_lds) {
-            p->last_scan_kernel = "k_scan_lds";
-            static const int ls_env = getenv("CSLAM_SCAN_LS") ? atoi(getenv("CSLAM_SCAN_LS")) : 0;
-            static const int bpc_env = getenv("CSLAM_SCAN_BPC") ? atoi(getenv("CSLAM_SCAN_BPC")) : 0;
-            const int LS = ls_env == 2 ? 2 : 1;
-            const int bpc = bpc_env > 0 ? bpc_env : 2;
-            constexpr int NW = 8;
-            int64_t strips = (p->vn + 15) / 16;
-            int64_t blocks = (strips + NW - 1) / NW;
-            if (blocks > (int64_t)p->cus * bpc) blocks = (int64_t)p->cus * bpc;
-            if (blocks < 1) blocks = 1;
-            const int64_t nw = blocks * NW < p->vn ? blocks * NW : (p->vn > 0 ? p->vn : 1);
-            const int64_t rows_max = (p->vn + nw - 1) / nw;
-            const int ngroups = (int)((rows_max + 16 * LS - 1) / (16 * LS));
-            if (LS == 2)
-                hipLaunchKernelGGL((k_scan_lds<2, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
-                                   p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
-                                   dots_stride, nw, ngroups);
-            else
-                hipLaunchKernelGGL((k_scan_lds<1, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st,
-                                   p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
-                                   dots_stride, nw, ngroups);
         } else {
             static const int u_env = getenv("CSLAM_SCAN_U") ? atoi(getenv("CSLAM_SCAN_U")) : 0;
             const int U = u_env == 8 ? 8 : 4;
@@ -2446,6 +2082,7 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
         return fail(CSLAM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     e = hipEventCreateWithFlags(&p->dev_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->app_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         cslam_pool_destroy(p);
         return fail(CSLAM_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
@@ -2464,7 +2101,9 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     (void)hipSetDevice(p->device);
     if (p->dev_pending) (void)hipEventSynchronize(p->dev_ev);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->app_pending) (void)hipEventSynchronize(p->app_ev);
     if (p->dev_ev) (void)hipEventDestroy(p->dev_ev);
+    if (p->app_ev) (void)hipEventDestroy(p->app_ev);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     if (p->rows) (void)hipFree(p->rows);
     if (p->inv_norm) (void)hipFree(p->inv_norm);
@@ -2475,7 +2114,6 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_b.release();
     p->cand_c.release();
     p->comp.release();
-    p->fault.release();
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();
@@ -2564,6 +2202,7 @@ int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float*
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
+    if (p->app_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->app_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     CSLAM_HIP_TRY(hipMemcpy2D(out, (size_t)p->dim * sizeof(float), p->rows + first * p->xs,
                               (size_t)p->xs * sizeof(float), (size_t)p->dim * sizeof(float),
@@ -2577,6 +2216,7 @@ int cslam_pool_read_inv_norms(const cslam_pool_t* p, int64_t first, int64_t n, f
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
+    if (p->app_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->app_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
     CSLAM_HIP_TRY(hipMemcpy(out, p->inv_norm + first, (size_t)n * sizeof(float),
                             hipMemcpyDeviceToHost));
@@ -2780,7 +2420,14 @@ int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64
         return fail(CSLAM_E_INVALID, "pool_append_on: bad args");
     if (n_rows == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
-    return append_rows_dev(p, rows_dev, n_rows, row_stride, st);
+    // Not ordered behind earlier scans (they read rows below their own window only, and a growth
+    // synchronises the device before it copies); every LATER pool call on another stream is
+    // ordered behind this append through app_ev (order_after_dev).
+    CSLAM_TRY(append_rows_dev(p, rows_dev, n_rows, row_stride, st));
+    CSLAM_HIP_TRY(hipEventRecord(p->app_ev, st));
+    p->app_stream = st;
+    p->app_pending = true;
+    return CSLAM_OK;
 }
 int pool_order_on(cslam_pool_t* p, hipStream_t st) {
     if (!p) return fail(CSLAM_E_INVALID, "pool_order_on: null");

@@ -255,16 +255,18 @@ int ensure_kf_capacity(cslam_shard* sh, int64_t want, hipStream_t st) {
     while (ncap < want) ncap *= 2;
     int32_t* nk = nullptr;
     CSLAM_TRY(dalloc(&nk, (size_t)ncap));
+    // Record kernels of earlier steps, queued on the MATCHING stream behind a scan, still write
+    // kf_of_row[n0 + i] into the old table (and read it): `st` (the exchange stream) is not ordered
+    // behind them, so the whole device drains BEFORE the old entries are copied — a copy enqueued
+    // first would lose those writes and later records would carry keyframe id -1
+    // (tests/test_shard_gpu.py::test_pipelined_keyframe_table_growth).
+    if (sh->kf_of_row) CSLAM_HIP_TRY(hipDeviceSynchronize());
     CSLAM_HIP_TRY(hipMemsetAsync(nk + sh->kf_cap, 0xFF, (size_t)(ncap - sh->kf_cap) * sizeof(int32_t), st));
-    if (sh->kf_of_row) {
+    if (sh->kf_of_row)
         CSLAM_HIP_TRY(hipMemcpyAsync(nk, sh->kf_of_row, (size_t)sh->kf_cap * sizeof(int32_t),
                                      hipMemcpyDeviceToDevice, st));
-        // record kernels of earlier steps may still read the old table on another stream
-        CSLAM_HIP_TRY(hipDeviceSynchronize());
-        CSLAM_HIP_TRY(hipFree(sh->kf_of_row));
-    } else {
-        CSLAM_HIP_TRY(hipStreamSynchronize(st));
-    }
+    CSLAM_HIP_TRY(hipStreamSynchronize(st));
+    if (sh->kf_of_row) CSLAM_HIP_TRY(hipFree(sh->kf_of_row));
     sh->kf_of_row = nk;
     sh->kf_cap = ncap;
     return CSLAM_OK;

@@ -2,7 +2,7 @@
 
 Same results as cslam/utils/misc.py:6-32 on every input the node produces (incl. the
 off-by-one of `list_range`, which the reference has and the traces pin)."""
-from itertools import dropwhile, islice
+from itertools import islice
 
 
 def clamp(num, min_value, max_value):

@@ -47,8 +47,9 @@ int cslam_device_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * Descriptor pool  — NearestNeighborsMatching state (nns_matching.py:9-21)
- * Rows are stored un-normalised, fp32, row-major with the row stride padded to a multiple of
- * 16 floats; 1/max(||x||,1e-8) is cached per row at add time.
+ * Rows are stored un-normalised, fp32, row-major, zero-padded to a multiple of 64 floats (16 for
+ * dim <= 16) plus 128 never-read floats when that stride is a multiple of 4 KiB (see
+ * cslam_pool_device_view); 1/max(||x||,1e-8) is cached per row at add time.
  * ------------------------------------------------------------------------------------------ */
 typedef struct cslam_pool cslam_pool_t;
 

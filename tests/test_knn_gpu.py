@@ -300,11 +300,12 @@ def test_device_append_is_ordered_before_host_api(gpu):
     m.close()
 
 
-def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
-    """CSLAM_SCAN_KERNEL=lds (block-synchronous LDS-staged query tiles), =pc (producer /
-    consumer LDS ring) and =dma (X streamed through LDS-DMA, forced here on a pool far below
-    its switch-over size: 209 one-strip panels, partial strips) must give the same bits as the
-    register-ring kernel: all four implement the one canonical order."""
+def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
+    """CSLAM_SCAN_KERNEL=ring (round 1's register-ring kernel) and the default LDS-DMA scan (here on
+    209 one-strip panels with partial strips) must give the same bits: both implement the one
+    canonical order.  (The LDS-staged and producer/consumer A/B variants of round 1 left the
+    product library in round 3; profiles/r01_scan_lds_vs_ring.txt, r01_scan_pc_variants.txt keep
+    their measurements.)"""
     import subprocess, sys, os, json
     code = (
         "import sys, json, numpy as np; sys.path.insert(0, '.');"
@@ -314,13 +315,13 @@ def test_lds_staged_scan_variant_is_bit_identical(gpu, monkeypatch):
         "m.add_items(X, list(range(3333))); r, s = m.search_batch(Q, 10);"
         "print(json.dumps([r.tolist(), s.view(np.int32).tolist()]))")
     outs = []
-    for kern in ("ring", "lds", "pc", "dma"):
+    for kern in ("ring", "dma"):
         env = dict(os.environ, CSLAM_SCAN_KERNEL=kern)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
         assert out.returncode == 0, out.stderr
         outs.append(json.loads(out.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert outs[0] == outs[1]
 
 
 @pytest.mark.parametrize("n,d,m,k", [
