@@ -93,7 +93,7 @@ int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64
 int pool_order_on(cslam_pool_t* p, hipStream_t st);
 // candidates of a split best-match scan, see knn.hip
 struct BestCandidates {
-    const uint64_t* a = nullptr;  // [16][stride] composites of rows < split, n valid per query
+    const uint64_t* a = nullptr;  // [m][stride] composites of rows < split, n valid per query
     const uint64_t* c = nullptr;  // ... of rows >= split
     int64_t stride = 0, n = 0;
 };

@@ -23,10 +23,10 @@
 
 #include "common.hpp"
 #include "composite.hpp"
+#include "dma_scan.hpp"
+#include "scan_mq.hpp"
 
 using namespace cslam;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -352,23 +352,6 @@ constexpr int kDmaStageB = 16 * kDmaPieceB;    // 16 rows x 256 floats
 // tools/small_n_sweep.py) — the ring kernel stays for descriptors of <= 16 floats and for 17-64 queries.
 constexpr int64_t kDmaMinRows = 1;
 
-__device__ inline void wait_vm_dyn(int n) {
-    // s_waitcnt takes an immediate: wave-uniform switch over the exact count (vmcnt is 6 bits;
-    // more than 48 younger operations cannot hide anything that is still needed here)
-#define CSLAM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n) {
-        CSLAM_W(0) CSLAM_W(1) CSLAM_W(2) CSLAM_W(3) CSLAM_W(4) CSLAM_W(5) CSLAM_W(6) CSLAM_W(7)
-        CSLAM_W(8) CSLAM_W(9) CSLAM_W(10) CSLAM_W(11) CSLAM_W(12) CSLAM_W(13) CSLAM_W(14)
-        CSLAM_W(15) CSLAM_W(16) CSLAM_W(17) CSLAM_W(18) CSLAM_W(19) CSLAM_W(20) CSLAM_W(21)
-        CSLAM_W(22) CSLAM_W(23) CSLAM_W(24) CSLAM_W(25) CSLAM_W(26) CSLAM_W(27) CSLAM_W(28)
-        CSLAM_W(29) CSLAM_W(30) CSLAM_W(31) CSLAM_W(32) CSLAM_W(33) CSLAM_W(34) CSLAM_W(35)
-        CSLAM_W(36) CSLAM_W(37) CSLAM_W(38) CSLAM_W(39) CSLAM_W(40) CSLAM_W(41) CSLAM_W(42)
-        CSLAM_W(43) CSLAM_W(44) CSLAM_W(45) CSLAM_W(46) CSLAM_W(47) CSLAM_W(48)
-        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-    }
-#undef CSLAM_W
-}
-
 // NB B fragments (one KW-float slice of the lane's query column, NB = KW / 16) by inline-asm
 // loads; the registers may only be read behind a counted wait followed by tie_b()
 template <int NB>
@@ -424,15 +407,6 @@ struct DmaCursor {   // position of a stage in a wave's work list
 //   holds global segment j ^ k) and the piece pitch is 1024 + 32 B (R <= 2) or 1024 + 64 B
 //   (R = 4), so that the 16 lanes of a ds_read_b128 pass — 16 rows at one k offset — hit 16
 //   different 16-B slots.  Same chain order, same folds: same bits.
-template <int KW>
-struct DmaGeom {
-    static constexpr int R = 256 / KW;                       // rows per DMA instruction
-    static constexpr int NB = KW / 16;                       // B fragments per slice
-    static constexpr int kPiece = 1024 + (R == 4 ? 64 : 32); // LDS bytes per piece
-    static constexpr int kStage = 16 * kPiece;               // 16 R rows x KW floats
-    static constexpr int kFold = 512 / KW;                   // slices per 512-float chunk
-};
-
 template <int NS, int NW, int NST, int AUX, bool BEST, int KW = 256>
 __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
                                                       int64_t n, int dp,
@@ -1399,7 +1373,7 @@ struct cslam_pool {
     float* rows = nullptr;      // [cap][dp]
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
-    DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp;
+    DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, part;
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
     PinBuf pin_rows;                   // pinned ring of cslam_pool_add's small appends
@@ -1726,6 +1700,138 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
     return CSLAM_OK;
 }
 
+// ---- the multi-tile LDS-DMA scan (scan_mq.hip): 17..80 queries per pass, the pool read once ----
+// CSLAM_SCAN_MQ=0 keeps round 2's register-ring passes (A/B runs).
+bool mq_scan_applies(const cslam_pool* p, int m) {
+    static const bool mq_env = !(getenv("CSLAM_SCAN_MQ") && atoi(getenv("CSLAM_SCAN_MQ")) == 0);
+    return mq_env && m > 16 && p->dp % 64 == 0 && p->vn > 0;
+}
+// queries of the next pass when `left` are still to do: as many tiles as a pass takes, the passes
+// of one call balanced (96 queries = 48 + 48, not 80 + 16: the pass is MFMA-bound from 3 tiles on)
+int mq_pass_queries(int left) {
+    const int cap = 16 * mq_max_tiles();
+    const int passes = (left + cap - 1) / cap;
+    const int per = (left + passes - 1) / passes;
+    const int mb = (per + 15) / 16 * 16;
+    return mb < left ? mb : left;
+}
+// A pass is either ONE launch (every wave whole strips of its block's even share) or, when the
+// strips do not divide evenly - 100k rows are 6250 strips for 1024 waves: 6.1 each, and the wave
+// with 7 sets the pace - a MAIN launch in which every wave takes exactly q strips, a K-SPLIT launch
+// for the remaining tail strips (blocks of 4 strips x 1/ks of the 512-float chunks, chunk partials
+// to a scratch array) and a combine launch that folds those in chunk order (same bits).
+struct MqPlan {
+    int tiles, kw, n_blocks, p_max;
+    int64_t n_main;      // rows of the main launch (all of them when there is no tail)
+    int tail_groups, tail_ks, nchunks;   // K-split tail: strip groups x K parts
+    int64_t tail_strips;
+    int64_t n_cand;      // composites per query (best-match mode)
+    bool nt;
+};
+MqPlan mq_plan(const cslam_pool* p, int m) {
+    static Knob k_tail{"CSLAM_MQ_TAIL", 1};
+    MqPlan g{};
+    g.tiles = (m + 15) / 16;
+    g.kw = p->dp % 128 == 0 ? 128 : 64;
+    g.nchunks = (p->dp + 511) / 512;
+    const int ns = mq_panel_strips(g.tiles);
+    const int64_t strips = (p->vn + 15) / 16;
+    const int64_t want = (strips + 3) / 4;   // a strip per wave at least
+    g.n_blocks = (int)(want < p->cus ? (want < 1 ? 1 : want) : p->cus);
+    g.n_main = p->vn;
+    const int64_t waves = 4 * (int64_t)g.n_blocks;
+    const int64_t q = strips / waves, tail = strips - q * waves;
+    if (knob(k_tail) && q >= 1 && tail > 0) {
+        // cost in strip times (one strip through all slices): q + 1 as one launch; with the tail
+        // K-split over ks parts: q + 1/ks + the extra launches (~5 us of ~10 us per chunk)
+        const int64_t groups = (tail + 3) / 4;
+        int64_t ks = p->cus / groups;
+        ks = ks < 1 ? 1 : (ks > g.nchunks ? g.nchunks : ks);
+        const double part_cost = (double)((g.nchunks + ks - 1) / ks) / g.nchunks + 0.6 / g.nchunks;
+        if (groups <= p->cus && part_cost < 0.8) {
+            g.n_main = 16 * q * waves;
+            g.tail_strips = tail;
+            g.tail_groups = (int)groups;
+            g.tail_ks = (int)ks;
+        }
+    }
+    const int64_t strips_main = (g.n_main + 15) / 16;
+    const int64_t strips_max = (strips_main + g.n_blocks - 1) / g.n_blocks;   // blocks take whole strips
+    g.p_max = (int)((strips_max + 4 * ns - 1) / (4 * ns));
+    g.n_cand = (int64_t)g.n_blocks * g.p_max * 4 + g.tail_strips;
+    g.nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
+    return g;
+}
+const char* mq_name(const MqPlan& g, bool best) {
+    static const char* const names[2][2][4] = {
+        {{"k_scan_mq<T=2,KW=128,NST=3>", "k_scan_mq<T=3,KW=128,NST=3>", "k_scan_mq<T=4,KW=128,NST=2>",
+          "k_scan_mq<T=5,KW=128,NST=2>"},
+         {"k_scan_mq<T=2,KW=64,NST=6>", "k_scan_mq<T=3,KW=64,NST=6>", "k_scan_mq<T=4,KW=64,NST=6>",
+          "k_scan_mq<T=5,KW=64,NST=6>"}},
+        {{"k_scan_mq<T=2,KW=128,NST=3,best>", "k_scan_mq<T=3,KW=128,NST=3,best>",
+          "k_scan_mq<T=4,KW=128,NST=2,best>", "k_scan_mq<T=5,KW=128,NST=2,best>"},
+         {"k_scan_mq<T=2,KW=64,NST=6,best>", "k_scan_mq<T=3,KW=64,NST=6,best>",
+          "k_scan_mq<T=4,KW=64,NST=6,best>", "k_scan_mq<T=5,KW=64,NST=6,best>"}}};
+    return names[best ? 1 : 0][g.kw == 128 ? 0 : 1][g.tiles - 2];
+}
+// stage `m` queries (17..80) and scan the window [v0, v0 + vn): raw dots, or (best) one composite
+// per query and panel in cand (and cand_c behind `split`, window-relative, when given)
+int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* rnq, float* dots,
+            int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride, int64_t split,
+            uint64_t* cand_c, const MqPlan& g, hipStream_t st) {
+    const int mq_pad = 16 * g.tiles;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim, m,
+                       mq_pad, p->dp, p->qstage.as<float>(), rnq, vec_ok, (int64_t)0);
+    CSLAM_HIP_TRY(hipGetLastError());
+    MqArgs a{};
+    a.X = p->rows + p->v0 * p->xs;
+    a.xs = p->xs;
+    a.n = g.n_main;
+    a.dp = p->dp;
+    a.Q = p->qstage.as<float>();
+    a.rnq = rnq;
+    a.m_valid = m;
+    a.dots = dots;
+    a.dots_stride = dots_stride;
+    a.n_blocks = g.n_blocks;
+    a.p_max = g.p_max;
+    a.device = p->device;
+    a.rnx = p->inv_norm + p->v0;
+    a.row0 = (uint32_t)p->v0;
+    a.cand = cand;
+    a.cand_stride = cand_stride;
+    a.split = (cand_c != nullptr && split >= 0) ? split : INT64_MAX;
+    a.cand_c = (cand_c != nullptr && split >= 0) ? cand_c : nullptr;
+    if (g.tail_strips > 0)
+        CSLAM_TRY(p->part.reserve((size_t)g.tail_strips * g.nchunks * g.tiles * 64 * sizeof(f32x4)));
+    bool prof = prof_take(p);
+    if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+    CSLAM_TRY(launch_scan_mq(a, g.tiles, g.kw, best ? kMqModeBest : kMqModeDots, g.nt, st));
+    if (g.tail_strips > 0) {
+        // the tail window [n_main, vn): K-split launch, then the fold + epilogue of its strips
+        MqArgs b = a;
+        b.X = a.X + g.n_main * p->xs;
+        b.n = p->vn - g.n_main;
+        b.rnx = a.rnx + g.n_main;
+        b.row0 = a.row0 + (uint32_t)g.n_main;
+        b.dots = dots ? dots + g.n_main : nullptr;
+        if (a.split != INT64_MAX) b.split = a.split - g.n_main;   // <= 0: every tail row is behind it
+        b.n_blocks = g.tail_groups;
+        b.p_max = 1;
+        b.part = p->part.as<f32x4>();
+        b.part_ks = g.tail_ks;
+        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.kw, kMqModePart, false, st));
+        CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * 4, st));
+    }
+    if (prof) {
+        CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
+        p->prof_n++;
+    }
+    p->last_scan_kernel = mq_name(g, best);
+    return CSLAM_OK;
+}
+
 // raw dots for queries [0,m) (device, arbitrary stride), m <= kQueryChunk; also fills
 // p->rnq[0..m) with 1/max(||q||,1e-8)
 int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* dots,
@@ -1743,7 +1849,18 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
     // (profiles/r01_scan_m_sweep.txt; one 16-query pass = 1): a 32-query pass 1.12, a 64-query
     // pass 1.85, a GEMM tile 3.2.  The scan wins up to ~200 queries except where the tiles fit
     // exactly (128), the GEMM beyond.
-    auto scan_cost = [](int mm) {
+    const bool mq = mq_scan_applies(p, m);
+    auto scan_cost = [mq](int mm) {
+        if (mq) {   // balanced passes of <= 80 queries on k_scan_mq (profiles/r03_m_sweep.txt)
+            static const double tile_cost[6] = {0.0, 1.0, 1.2, 1.5, 1.75, 2.1};
+            double c = 0.0;
+            for (int left = mm; left > 0;) {
+                const int mb = mq_pass_queries(left);
+                c += tile_cost[(mb + 15) / 16];
+                left -= mb;
+            }
+            return c;
+        }
         const int rem = mm % 64;
         return 1.85 * (mm / 64) + (rem == 0 ? 0.0 : rem <= 16 ? 1.0 : rem <= 32 ? 1.12 : 1.85);
     };
@@ -1834,8 +1951,16 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         }
         return CSLAM_OK;
     }
-    for (int q0 = 0; q0 < m; q0 += kMaxQueriesPerPass) {
-        int mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
+    for (int q0 = 0, mb = 0; q0 < m; q0 += mb) {
+        if (mq && m - q0 > 16) {
+            // 17..80 queries per pass on the multi-tile LDS-DMA scan: the pool is read once
+            mb = mq_pass_queries(m - q0);
+            CSLAM_TRY(mq_pass(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, p->rnq.as<float>() + q0,
+                              dots + (int64_t)q0 * dots_stride, dots_stride, false, nullptr, 0, -1,
+                              nullptr, mq_plan(p, mb), st));
+            continue;
+        }
+        mb = m - q0 < kMaxQueriesPerPass ? m - q0 : kMaxQueriesPerPass;
         int mq_pad = mb <= 16 ? 16 : (mb <= 32 ? 32 : 64);
         // the staging area is reused by every pass: stream order keeps pass i+1's staging
         // behind pass i's scan
@@ -1997,6 +2122,40 @@ int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_
     return CSLAM_OK;
 }
 
+// search_best of 17..~100 queries: k_scan_mq passes with the fused arg-max epilogue (one composite
+// per query and panel), then k_best_pair per pass - no dots round trip.  Both windows of a split
+// search (rows before / from `split`, window-relative) in the same pass.
+bool mq_best_applies(const cslam_pool* p, int m) {
+    // beyond two passes the 128-query GEMM tiles win (cost model in compute_dots)
+    return mq_scan_applies(p, m) && m <= 2 * 16 * mq_max_tiles() && (m <= 96 || m > 128);
+}
+int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
+                 int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {
+    CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+    CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+    for (int q0 = 0, mb = 0; q0 < m; q0 += mb) {
+        mb = mq_pass_queries(m - q0);
+        if (mb <= 16) {   // a last pass of <= 16 queries: the single-tile kernel
+            CSLAM_TRY(best_scan(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, split, idx_a + q0, sim_a + q0,
+                                idx_c ? idx_c + q0 : nullptr, sim_c ? sim_c + q0 : nullptr, st));
+            continue;
+        }
+        const MqPlan g = mq_plan(p, mb);
+        const int64_t cstride = (g.n_cand + 63) / 64 * 64;
+        CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+        if (split >= 0) CSLAM_TRY(p->cand_c.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+        CSLAM_TRY(mq_pass(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, p->rnq.as<float>() + q0, nullptr, 0,
+                          true, p->cand_a.as<uint64_t>(), cstride, split,
+                          split >= 0 ? p->cand_c.as<uint64_t>() : nullptr, g, st));
+        hipLaunchKernelGGL(k_best_pair, dim3(mb, split >= 0 ? 2 : 1), dim3(256), 0, st,
+                           p->cand_a.as<uint64_t>(), p->cand_c.as<uint64_t>(), cstride, g.n_cand,
+                           idx_a + q0, sim_a + q0, idx_c ? idx_c + q0 : nullptr,
+                           sim_c ? sim_c + q0 : nullptr);
+        CSLAM_HIP_TRY(hipGetLastError());
+    }
+    return CSLAM_OK;
+}
+
 int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k,
                     int32_t* out_idx, float* out_sim, hipStream_t st, int64_t row_lo = 0,
                     int64_t row_hi = -1) {
@@ -2014,6 +2173,8 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     }
     if (k == 1 && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m))
         return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
+    if (k == 1 && mq_best_applies(p, m))
+        return best_scan_mq(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
     int64_t sims_stride = (p->vn + 63) / 64 * 64;
     const int64_t qc = query_chunk(sims_stride);
     int64_t chunk = m < qc ? m : qc;
@@ -2114,6 +2275,7 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_b.release();
     p->cand_c.release();
     p->comp.release();
+    p->part.release();
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();
@@ -2274,7 +2436,11 @@ int cslam_pool_search_best_split_dev(cslam_pool_t* p, const float* queries_dev, 
     CSLAM_TRY(order_after_dev(p, st));
     p->v0 = 0;
     p->vn = row_hi;
-    if (split_row > 0 && split_row < row_hi && dma_scan_applies(p)) {
+    if (split_row > 0 && split_row < row_hi && n_queries > 16 && mq_best_applies(p, n_queries)) {
+        // 17..80 queries per pass, both sides in the same pass
+        CSLAM_TRY(best_scan_mq(p, queries_dev, query_stride, n_queries, split_row, idx_a_dev, sim_a_dev,
+                               idx_c_dev, sim_c_dev, st));
+    } else if (split_row > 0 && split_row < row_hi && dma_scan_applies(p)) {
         // one scan launch per 16 queries answers both sides
         for (int q0 = 0; q0 < n_queries; q0 += 16) {
             const int mb = n_queries - q0 < 16 ? n_queries - q0 : 16;
@@ -2438,12 +2604,30 @@ int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_
                                int64_t split_row, int64_t row_hi, hipStream_t st,
                                BestCandidates* out, bool* applied) {
     *applied = false;
-    if (!p || m < 1 || m > 16 || split_row <= 0 || split_row >= row_hi || row_hi > p->n ||
+    if (!p || m < 1 || m > 16 * mq_max_tiles() || split_row <= 0 || split_row >= row_hi || row_hi > p->n ||
         !queries_dev || query_stride < p->dim)
         return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     p->v0 = 0;
     p->vn = row_hi;
+    if (m > 16) {   // one k_scan_mq pass: 17..80 gathered descriptors (8 robots x 10 per message)
+        if (!mq_scan_applies(p, m)) return CSLAM_OK;
+        CSLAM_TRY(order_after_dev(p, st));
+        CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+        CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+        const MqPlan g = mq_plan(p, m);
+        const int64_t cstride = (g.n_cand + 63) / 64 * 64;
+        CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+        CSLAM_TRY(p->cand_c.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+        CSLAM_TRY(mq_pass(p, queries_dev, query_stride, m, p->rnq.as<float>(), nullptr, 0, true,
+                          p->cand_a.as<uint64_t>(), cstride, split_row, p->cand_c.as<uint64_t>(), g, st));
+        out->a = p->cand_a.as<uint64_t>();
+        out->c = p->cand_c.as<uint64_t>();
+        out->stride = cstride;
+        out->n = g.n_cand;
+        *applied = true;
+        return mark_dev(p, st);
+    }
     if (!dma_scan_applies(p)) return CSLAM_OK;
     CSLAM_TRY(order_after_dev(p, st));
     CSLAM_TRY(best_scan_candidates(p, queries_dev, query_stride, m, split_row, &out->stride, &out->n, st));

@@ -1,0 +1,574 @@
+// scan_mq.hip — k_scan_mq: the pool scan for 17..80 queries per pass (T = 2..5 tiles of 16), X
+// streamed ONCE through LDS-DMA whatever the number of query tiles.
+//
+// Replaces, for mid-size batches, what cslam/nns_matching.py:57-63 does per query (one full read of
+// the pool each): the sharded step of SURVEY.md §8e matches all R x detection_publication_max_elems
+// gathered descriptors (8 x 10 = 80, cslam/loop_closure_detection_node.py:34) against the pool in one
+// pass.  Round 2 ran 17..64 queries on the register-ring kernel (16 rows x 64 B per load
+// instruction, pool read twice for 80 queries: 0.83 ms = 0.50 of the fp32-MFMA peak).
+//
+// Structure (one 256-thread block per CU, four waves = one per SIMD):
+//   * every wave owns a row panel of <= NS strips (16 rows each) per round and a PRIVATE ring of
+//     NST stages (16 rows x KW floats, LDS-DMA pieces of 1 KiB, DmaGeom<KW>), ordered only by its own
+//     counted vmcnt - exactly the X side of k_scan_dma;
+//   * the query block is SHARED: the KW-float slice of all 16 T staged queries sits in LDS (double
+//     buffered, moved by LDS-DMA too, every wave a quarter of the pieces), one raw s_barrier per
+//     slice step.  B fragments go LDS -> VGPR per k-block, so they cost 4 T registers instead of the
+//     128 T of k_scan_dma's register-resident slice - that is what makes T > 1 fit;
+//   * work order is slice-major inside the panel (the step = one slice for all strips of all four
+//     waves), accumulators acc/tot[NS][T] stay in registers (AccVGPRs) for the whole panel;
+//   * the A fragments of a stage (NB float4 per lane) are refreshed IN PLACE: once k-block i of
+//     stage j is multiplied, a[i] is re-read from stage j+1's slot - no second register set, no
+//     exposed LDS latency between stages; stage j+NST is issued into stage j's slot in pieces
+//     between the k-blocks (a burst of DMA issues keeps the matrix pipe idle).
+// Numerics: per (row, query) the MFMA chain visits k in the canonical order of DESIGN.md §3, T
+// tiles interleave their independent chains, folds every 512 floats -> bit-identical to every
+// other scan (tests/test_knn_gpu.py).
+//
+// MODE_DOTS raw dots out; MODE_BEST (k = 1): one (similarity, row) composite per query and panel
+// (+ the split window of csrc/shard.hip); MODE_PART: the block multiplies only the 512-float
+// chunks [chunk_lo, chunk_hi) of its rows and leaves every chunk's partial in a scratch array -
+// the K-split tail / small-pool pass, folded in chunk order by k_mq_combine (same bits).
+#include "common.hpp"
+#include "composite.hpp"
+#include "dma_scan.hpp"
+#include "scan_mq.hpp"
+
+using namespace cslam;
+
+namespace {
+
+constexpr int MODE_DOTS = 0, MODE_BEST = 1, MODE_PART = 2;
+
+template <int T, int KW, int NST, int NS, int AUX, int MODE>
+__global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
+    using GM = DmaGeom<KW>;
+    constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece;
+    constexpr int NP = 16 / R;            // DMA pieces per 16-row stage (== NB)
+    constexpr int kStage = NP * kPiece;   // 16 rows x KW floats
+    constexpr int kFold = 512 / KW;       // slices per 512-float chunk
+    constexpr int NBP = T * NP / 4;       // B pieces per wave and slice
+    constexpr int RV = MODE == MODE_BEST ? 2 : 0;   // row-norm loads per step
+    // The refill of a slot (stage j + NST into stage j's slot) is issued behind the k-blocks of
+    // stage j, PPK pieces per k-block; in front of k-block WP the NEXT stage must have landed and
+    // the A fragments consumed so far are refreshed from it.  Two stages per wave (T >= 4: the LDS
+    // holds no more beside the query slices): two pieces per k-block and a late wait, so that the
+    // last piece of a stage has (NB/2 + WP) / NB of a stage time to land.
+    constexpr int PPK = NST == 2 ? 2 : 1;
+    constexpr int WP = NB - 2;
+    constexpr int kIssuedAtWP = PPK * WP < NP ? PPK * WP : NP;
+    static_assert(NP == NB && (T * NP) % 4 == 0 && NB >= 4, "geometry");
+    extern __shared__ __attribute__((aligned(16))) char mq_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    char* ring = mq_lds + wave * NST * kStage;
+    char* bbuf = mq_lds + 4 * NST * kStage;   // [2][T][kStage]
+    const int nkc_all = A.dp / KW;
+    // MODE_PART (K-split launch): grid = n_blocks strip groups x part_ks K parts; this block multiplies
+    // the whole 512-float chunks [chunk_lo, chunk_hi) of its rows only
+    const int bidx = MODE == MODE_PART ? (int)(blockIdx.x % (unsigned)A.n_blocks) : (int)blockIdx.x;
+    const int kpart = MODE == MODE_PART ? (int)(blockIdx.x / (unsigned)A.n_blocks) : 0;
+    const int nchunks_all = (nkc_all + kFold - 1) / kFold;
+    const int chunk_lo = MODE == MODE_PART ? kpart * nchunks_all / A.part_ks : 0;
+    const int chunk_hi = MODE == MODE_PART ? (kpart + 1) * nchunks_all / A.part_ks : nchunks_all;
+    const int kc_begin = chunk_lo * kFold;
+    const int kc_end = chunk_hi * kFold < nkc_all ? chunk_hi * kFold : nkc_all;
+    const int nkc = kc_end - kc_begin;
+
+    // Rows are dealt out in whole 16-row strips (a partial strip costs a whole one on the matrix
+    // pipe): the block's strips are an even split of the window's, walked in P rounds of four
+    // panels (one per wave) of <= NS strips.  Only the window's last strip can be partial.
+    const int64_t S = (A.n + 15) >> 4;
+    const int64_t bq = S / A.n_blocks, brem = S - bq * A.n_blocks;
+    const int64_t bs_lo = (int64_t)bidx * bq + (bidx < brem ? bidx : brem);
+    const int bs = (int)(bq + (bidx < brem ? 1 : 0));   // strips of this block
+    if (bs == 0 || nkc <= 0) return;   // block-uniform
+    const int P = (bs + 4 * NS - 1) / (4 * NS);
+    const int npan = 4 * P;
+    const int pq = bs / npan, prem = bs - pq * npan;
+    auto panel_s0 = [&](int q) { return bs_lo + (int64_t)q * pq + (q < prem ? q : prem); };   // first strip
+    auto panel_lo = [&](int q) { return panel_s0(q) << 4; };
+    auto panel_rows = [&](int rd) {
+        const int q = 4 * rd + wave;
+        const int64_t lo = panel_lo(q);
+        int64_t hi = panel_lo(q + 1);
+        hi = hi < A.n ? hi : A.n;
+        return (int)(hi > lo ? hi - lo : 0);
+    };
+
+    // stages of this wave: sum over rounds of strips x slices
+    int J = 0;
+    for (int rd = 0; rd < P; ++rd) J += ((panel_rows(rd) + 15) >> 4) * nkc;
+
+    // DMA lane roles: lane l moves segment seg of row `sub` of a piece (R rows x KW floats)
+    const int sub = R == 1 ? 0 : lane / (64 / R);
+    const int seg = R == 1 ? lane : ((lane & (64 / R - 1)) ^ sub);
+    // reader: row r of a stage sits in piece r / R as row r % R
+    const int rd_off = (r / R) * kPiece + (r % R) * (KW * 4) + ((g ^ (r % R)) * 16);
+    const uint32_t xs_b = (uint32_t)(A.xs * 4);   // row stride in bytes (< 2^20)
+
+    // ---- issue side ---------------------------------------------------------------------------
+    // Every wave issues the SAME operations per step and per stage whatever its rows (the refill
+    // of a slot nobody will read again repeats the wave's last stage), so the waits of the stage
+    // loop are compile-time counts; only the wait for the B pieces (the number of stages a step
+    // holds varies) and the one for the row norms are counted at run time.
+    int issued = 0;       // vector-memory operations issued by this wave so far
+    int mark_b = 0, mark_rv = 0;
+    // issue cursor: (round, slice, strip) of the next stage to request; stays on the last one.
+    // i_base (uniform) = first row of that stage at its slice; i_last = rows of the panel behind the
+    // stage's first row, minus one (the clamp of a ragged last strip)
+    int i_rd = 0, i_kc = 0, i_s = 0, i_left = J;
+    int i_ns = 1, i_last = 0;
+    const char* i_base = reinterpret_cast<const char*>(A.X + (int64_t)kc_begin * KW);   // J == 0: row 0, dummy
+    const int64_t strip_b = 16 * (int64_t)xs_b;
+    auto i_panel = [&]() {   // first stage of the next round in which this wave has rows
+        while (i_rd < P) {
+            const int rows = panel_rows(i_rd);
+            if (rows > 0) {
+                i_ns = (rows + 15) >> 4;
+                i_last = rows - 1;
+                i_base = reinterpret_cast<const char*>(A.X + panel_lo(4 * i_rd + wave) * A.xs + (int64_t)kc_begin * KW);
+                break;
+            }
+            ++i_rd;
+        }
+    };
+    if (J > 0) i_panel();
+    // piece pp of the stage under the issue cursor -> slot `sl`; rows past the panel's end repeat
+    // its last row (clamped: never an address outside the window, results never looked at)
+    auto issue_piece = [&](int pp, int sl) {
+        int rel = R * pp + sub;
+        rel = rel < i_last ? rel : i_last;
+        const uint32_t off = (uint32_t)rel * xs_b + (uint32_t)seg * 16u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(i_base + off),
+                                         (__attribute__((address_space(3))) void*)(ring + sl * kStage + pp * kPiece),
+                                         16, 0, AUX);
+    };
+    auto i_advance = [&]() {
+        if (i_left <= 1) {   // nothing behind the last stage: the cursor stays (dummy refills)
+            i_left = 0;
+            return;
+        }
+        --i_left;
+        if (++i_s < i_ns) {            // next strip of the slice
+            i_base += strip_b;
+            i_last -= 16;
+            return;
+        }
+        i_base -= (int64_t)(i_s - 1) * strip_b;   // back to the panel's first strip
+        i_last += 16 * (i_s - 1);
+        i_s = 0;
+        if (++i_kc < nkc) {            // next slice
+            i_base += KW * 4;
+            return;
+        }
+        i_kc = 0;
+        ++i_rd;
+        i_panel();
+    };
+    // this wave's quarter of the B pieces of slice kc -> buffer bb
+    auto issue_b = [&](int kc, int bb) {
+#pragma unroll
+        for (int x = 0; x < NBP; ++x) {
+            const int pi = wave * NBP + x;          // piece of the slice: tile pi / NP, piece pi % NP
+            const int t = pi / NP, pp = pi % NP;
+            const float* a = A.Q + (int64_t)(16 * t + R * pp + sub) * A.dp + (kc_begin + kc) * KW + seg * 4;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)a,
+                (__attribute__((address_space(3))) void*)(bbuf + (bb * T + t) * kStage + pp * kPiece), 16, 0, 0);
+        }
+        issued += NBP;
+        mark_b = issued;
+    };
+
+    // ---- prologue -----------------------------------------------------------------------------
+    // MODE_BEST: 1 / ||q|| of this lane's query column in every tile.  Inline-asm loads, waited for
+    // here: an ordinary load makes hipcc drain vmcnt(0) - the whole ring - at its first use.
+    float rq[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        rq[t] = 0.f;
+        if (MODE == MODE_BEST)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(rq[t]) : "v"(A.rnq + 16 * t + r) : "memory");
+    }
+    if (MODE == MODE_BEST) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < T; ++t) asm volatile("" : "+v"(rq[t]));
+    }
+    issue_b(0, 0);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) issue_piece(pp, i);
+        issued += NP;
+        i_advance();
+    }
+    f32x4 a[NB];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * NP) : "memory");   // stage 0 has landed
+#pragma unroll
+    for (int i = 0; i < NB; ++i) a[i] = *reinterpret_cast<const f32x4*>(ring + rd_off + i * 64);
+
+    int slot = 0;      // ring slot of the stage the consumer is at
+    int gstep = 0;
+    for (int rd = 0; rd < P; ++rd) {
+        const int rows = panel_rows(rd);
+        const int64_t lo = panel_lo(4 * rd + wave);
+        const int ns = (rows + 15) >> 4;
+        f32x4 acc[NS][T], tot[NS][T];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // both live in AccVGPRs across the panel (left to itself hipcc parks them in
+                // architectural VGPRs between a strip's stages - 8 NS T of them - and spills)
+                asm volatile("" : "+a"(acc[s][t]), "+a"(tot[s][t]));
+            }
+        float rv0 = 0.f, rv1 = 0.f;   // MODE_BEST: 1/||x|| of the panel's rows, one row per lane
+        for (int kc = 0; kc < nkc; ++kc, ++gstep) {
+            const int bb = gstep & 1;
+            // my B pieces of this slice have landed ... and so have everybody's; everybody is also
+            // done with the other buffer (slice kc - 1)
+            wait_vm_dyn(issued - mark_b);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (MODE == MODE_BEST) {
+                // 1/||x|| of the panel's <= 128 rows for the epilogue, lane l rows lo + l and
+                // lo + 64 + l (clamped into the window).  Issued at EVERY step, unconditionally (an
+                // asm load inside a conditional leaves the compiler free to copy its not-yet-written
+                // output at the join); waited for and tied in front of the epilogue.
+                int64_t i0 = lo + lane, i1 = lo + 64 + lane;
+                i0 = i0 < A.n ? i0 : A.n - 1;
+                i1 = i1 < A.n ? i1 : A.n - 1;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(rv0) : "v"(A.rnx + i0) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(rv1) : "v"(A.rnx + i1) : "memory");
+                issued += 2;
+                mark_rv = issued;
+            }
+            // slice kc + 1 (slice 0 again behind the last one: the next round's first, or nobody's)
+            issue_b(kc + 1 == nkc ? 0 : kc + 1, bb ^ 1);
+            const char* bs = bbuf + bb * T * kStage + rd_off;
+            // end of a 512-float chunk / of the row: fold (or, MODE_PART, hand the partial over)
+            const bool fold = (((kc_begin + kc + 1) & (kFold - 1)) == 0) || kc_begin + kc + 1 == nkc_all;
+            f32x4 bcur[T];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    // `a` holds this stage (read while the previous one was multiplied).  Its slot is
+                    // refilled piece by piece BEHIND the k-blocks: the first DMA follows MFMAs that
+                    // waited for B fragments read after the last of those `a` reads - LDS returns in
+                    // order, so every read of the slot has returned before anything overwrites it.
+                    const int nslot = slot + 1 == NST ? 0 : slot + 1;
+                    const char* nx = ring + nslot * kStage + rd_off;
+                    if (s == 0) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        // B fragments of the next k-block (of k-block 0 behind the last: the next
+                        // strip of this step starts with them)
+                        f32x4 bnx[T];
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            bnx[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage + (i + 1 < NB ? i + 1 : 0) * 64);
+                        if (i == WP) {
+                            // The next stage has landed.  Younger than its last piece: the stages
+                            // behind it in the ring, this stage's refill so far, and the step-top
+                            // operations when a step began since (at least then: fewer strips per
+                            // step only make the count an under-estimate, i.e. a longer wait).
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP + kIssuedAtWP + (s <= NST - 2 ? NBP + RV : 0))
+                                         : "memory");
+#pragma unroll
+                            for (int i2 = 0; i2 < WP; ++i2)
+                                a[i2] = *reinterpret_cast<const f32x4*>(nx + i2 * 64);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int t = 0; t < T; ++t)
+                                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bcur[t][j], acc[s][t], 0, 0, 0);
+                        if (i >= WP) a[i] = *reinterpret_cast<const f32x4*>(nx + i * 64);
+#pragma unroll
+                        for (int x = 0; x < PPK; ++x)
+                            if (PPK * i + x < NP) issue_piece(PPK * i + x, slot);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
+                    }
+                    issued += NP;
+                    i_advance();
+#pragma unroll
+                    for (int t = 0; t < T; ++t) asm volatile("" : "+a"(acc[s][t]));
+                    if (fold) {
+                        if (MODE == MODE_PART) {
+                            // the partial of chunk c of this strip, in the layout k_mq_combine folds
+                            const int64_t strip = (lo >> 4) + s;   // panels are strip-aligned
+                            const int c = (kc_begin + kc) / kFold;
+                            f32x4* out = A.part + ((strip * nchunks_all + c) * T) * 64 + lane;
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                out[t * 64] = acc[s][t];
+                                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                asm volatile("" : "+a"(acc[s][t]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                tot[s][t] = tot[s][t] + acc[s][t];
+                                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                asm volatile("" : "+a"(acc[s][t]), "+a"(tot[s][t]));
+                            }
+                        }
+                    }
+                    slot = nslot;
+                }
+            }
+        }
+        // ---- panel epilogue ---------------------------------------------------------------
+        if (MODE == MODE_BEST) {
+            wait_vm_dyn(issued - mark_rv);
+            asm volatile("" : "+v"(rv0), "+v"(rv1));
+            uint64_t best[T], best_c[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) best[t] = best_c[t] = 0;
+            if (ns > 0) {
+                const int64_t hi = lo + rows;
+                const bool two = A.split < hi;   // wave-uniform: rows >= split in this panel
+                const uint32_t rbase = A.row0 + (uint32_t)lo;
+                const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s < ns) {
+                        float rn[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, 64);
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int rel = 16 * s + 4 * g + e;
+                                const float sim = (tot[s][t][e] * rn[e]) * rq[t];
+                                uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+                                c = rel < rows ? c : 0;
+                                if (two) {
+                                    const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
+                                    best[t] = ca > best[t] ? ca : best[t];
+                                    best_c[t] = cc > best_c[t] ? cc : best_c[t];
+                                } else {
+                                    best[t] = c > best[t] ? c : best[t];
+                                }
+                            }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    uint64_t o = __shfl_xor(best[t], 16, 64);
+                    best[t] = o > best[t] ? o : best[t];
+                    o = __shfl_xor(best[t], 32, 64);
+                    best[t] = o > best[t] ? o : best[t];
+                    if (two) {
+                        o = __shfl_xor(best_c[t], 16, 64);
+                        best_c[t] = o > best_c[t] ? o : best_c[t];
+                        o = __shfl_xor(best_c[t], 32, 64);
+                        best_c[t] = o > best_c[t] ? o : best_c[t];
+                    }
+                }
+            }
+            // one composite per query and panel; a panel without rows leaves the empty composite
+            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * 4 + wave;
+            if (g == 0) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (16 * t + r < A.m_valid) {
+                        A.cand[(int64_t)(16 * t + r) * A.cand_stride + pidx] = best[t];
+                        if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + pidx] = best_c[t];
+                    }
+            }
+        } else if (MODE == MODE_DOTS) {
+            const int64_t hi = lo + rows;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s < ns) {
+                    const int64_t r0 = lo + 16 * s + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (16 * t + r < A.m_valid) {
+                            float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (r0 + e < hi) out[e] = tot[s][t][e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_BEST && g == 0) {   // rounds this block does not have (blocks differ by one row)
+        for (int rd = P; rd < A.p_max; ++rd) {
+            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * 4 + wave;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (16 * t + r < A.m_valid) {
+                    A.cand[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
+                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mq_combine: the K-split pass left, per strip and 512-float chunk, the chunk's partial products
+// ([strip][chunk][tile][lane] float4 in the MFMA accumulator layout).  One wave per strip folds them
+// in chunk order - tot = ((0 + c0) + c1) + ... exactly the fold of k_scan_mq's registers, same bits -
+// and runs the same epilogue: raw dots, or the strip's (similarity, row) composite per query.
+// ---------------------------------------------------------------------------------------------
+template <bool BEST>
+__global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, int nchunks, int64_t cand_off) {
+    const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t lo = strip << 4;
+    if (lo >= A.n) return;
+    const int64_t hi = lo + 16 < A.n ? lo + 16 : A.n;
+    const int rows = (int)(hi - lo);
+    f32x4 tot[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* src = A.part + (strip * nchunks) * tiles * 64 + lane;
+    for (int c = 0; c < nchunks; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (t < tiles) tot[t] = tot[t] + src[((int64_t)c * tiles + t) * 64];
+    if (BEST) {
+        float rn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = lo + 4 * g + e;
+            rn[e] = A.rnx[row < A.n ? row : A.n - 1];
+        }
+        const bool two = A.split < hi;
+        const uint32_t rbase = A.row0 + (uint32_t)lo;
+        const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t < tiles) {
+                const float rq = A.rnq[16 * t + r];
+                uint64_t best = 0, best_c = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rel = 4 * g + e;
+                    const float sim = (tot[t][e] * rn[e]) * rq;
+                    uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+                    c = rel < rows ? c : 0;
+                    if (two) {
+                        const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
+                        best = ca > best ? ca : best;
+                        best_c = cc > best_c ? cc : best_c;
+                    } else {
+                        best = c > best ? c : best;
+                    }
+                }
+                uint64_t o = __shfl_xor(best, 16, 64);
+                best = o > best ? o : best;
+                o = __shfl_xor(best, 32, 64);
+                best = o > best ? o : best;
+                o = __shfl_xor(best_c, 16, 64);
+                best_c = o > best_c ? o : best_c;
+                o = __shfl_xor(best_c, 32, 64);
+                best_c = o > best_c ? o : best_c;
+                if (g == 0 && 16 * t + r < A.m_valid) {
+                    A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best;
+                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best_c;
+                }
+            }
+        }
+    } else {
+        const int64_t r0 = lo + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t < tiles && 16 * t + r < A.m_valid) {
+                float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < hi) out[e] = tot[t][e];
+            }
+        }
+    }
+}
+
+// LDS bytes of a variant
+template <int T, int KW, int NST>
+constexpr size_t mq_lds_bytes() {
+    return (size_t)(4 * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece;
+}
+
+template <int T, int KW, int NST, int NS, int AUX, int MODE>
+int launch_one(const MqArgs& a, hipStream_t st) {
+    constexpr size_t lds = mq_lds_bytes<T, KW, NST>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set[64] = {};
+    if (!attr_set[a.device & 63]) {
+        CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_mq<T, KW, NST, NS, AUX, MODE>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[a.device & 63] = true;
+    }
+    const unsigned grid = (unsigned)a.n_blocks * (MODE == MODE_PART ? (unsigned)a.part_ks : 1u);
+    hipLaunchKernelGGL((k_scan_mq<T, KW, NST, NS, AUX, MODE>), dim3(grid), dim3(256), lds, st, a);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+template <int T, int KW, int NST, int NS>
+int launch_mode(const MqArgs& a, int mode, bool nt, hipStream_t st) {
+    if (mode == MODE_PART) return launch_one<T, KW, NST, NS, 0, MODE_PART>(a, st);
+    if (mode == MODE_BEST)
+        return nt ? launch_one<T, KW, NST, NS, 2, MODE_BEST>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_BEST>(a, st);
+    return nt ? launch_one<T, KW, NST, NS, 2, MODE_DOTS>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_DOTS>(a, st);
+}
+
+}  // namespace
+
+namespace cslam {
+
+int mq_max_tiles() { return 5; }
+int mq_panel_strips(int tiles) { return tiles >= 5 ? 6 : 8; }
+
+int launch_scan_mq(const MqArgs& a, int tiles, int kw, int mode, bool nt, hipStream_t st) {
+    if (mode == kMqModePart && a.part_ks < 1) return fail(CSLAM_E_INVALID, "scan_mq: K parts");
+    if (tiles < 2 || tiles > 5 || (kw != 128 && kw != 64) || a.dp % kw != 0 || a.n <= 0 || a.n_blocks < 1)
+        return fail(CSLAM_E_INVALID, "scan_mq: bad launch (tiles %d, slice %d, rows %lld)", tiles, kw,
+                    (long long)a.n);
+    if (kw == 128) {
+        switch (tiles) {
+            case 2: return launch_mode<2, 128, 3, 8>(a, mode, nt, st);
+            case 3: return launch_mode<3, 128, 3, 8>(a, mode, nt, st);
+            case 4: return launch_mode<4, 128, 2, 8>(a, mode, nt, st);
+            default: return launch_mode<5, 128, 2, 6>(a, mode, nt, st);
+        }
+    }
+    switch (tiles) {
+        case 2: return launch_mode<2, 64, 6, 8>(a, mode, nt, st);
+        case 3: return launch_mode<3, 64, 6, 8>(a, mode, nt, st);
+        case 4: return launch_mode<4, 64, 6, 8>(a, mode, nt, st);
+        default: return launch_mode<5, 64, 6, 6>(a, mode, nt, st);
+    }
+}
+
+int launch_mq_combine(const MqArgs& a, int tiles, int nchunks, bool best, int64_t cand_off, hipStream_t st) {
+    const int64_t strips = (a.n + 15) >> 4;
+    if (strips <= 0) return CSLAM_OK;
+    const unsigned grid = (unsigned)((strips + 3) / 4);
+    if (best)
+        hipLaunchKernelGGL((k_mq_combine<true>), dim3(grid), dim3(256), 0, st, a, tiles, nchunks, cand_off);
+    else
+        hipLaunchKernelGGL((k_mq_combine<false>), dim3(grid), dim3(256), 0, st, a, tiles, nchunks, cand_off);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+}  // namespace cslam

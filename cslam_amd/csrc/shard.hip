@@ -231,7 +231,7 @@ struct cslam_shard {
     int me = 0, R = 1, b_max = 0, dim = 0, device = 0;
     int k_local = 0, min_inbetween = 0, K = 1;
     bool fused = true;
-    bool best2 = false;  // no intra-robot matching, <= 16 gathered descriptors: split best-match scan
+    bool best2 = false;  // no intra-robot matching, <= 80 gathered descriptors: ONE split best-match scan pass
     double thr = 0.0;
     int32_t* kf_of_row = nullptr;
     int64_t kf_cap = 0;
@@ -307,7 +307,7 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
     // inter-robot matching only (frontend.enable_intra_robot_loop_closures = false, the node's
     // default, loop_closure_detection_node.py:36) asks two questions per gathered descriptor — best
     // old row, best row of the new block: one split best-match scan, no top-K lists
-    sh->best2 = nb_best_matches == 0 && (int64_t)nb_robots * max_block <= 16;
+    sh->best2 = nb_best_matches == 0 && (int64_t)nb_robots * max_block <= 80;   // one scan pass (scan_mq.hip)
     sh->rec_slots = 3 * (int64_t)nb_robots * max_block;
     int rc = CSLAM_OK;
     hipError_t e = hipSetDevice(sh->device);

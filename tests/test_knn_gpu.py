@@ -368,6 +368,116 @@ def test_dma_scan_matches_oracle(gpu, n, d, m, k):
     mt.close()
 
 
+@pytest.mark.parametrize("n,d,m,k", [
+    # 4096-d (cfg2 / cfg4 row shape): every tile count, ragged query counts, k = 1 (fused arg-max
+    # epilogue) and k > 1 (raw dots + select)
+    (9000, 4096, 17, 1), (9000, 4096, 33, 1), (9000, 4096, 48, 1), (9000, 4096, 64, 1),
+    (9000, 4096, 80, 1), (9000, 4096, 96, 1),          # 96 = two balanced passes of 48
+    (9000, 4096, 17, 10), (5000, 4096, 48, 3), (5000, 4096, 80, 10),
+    # 128-d: the reference's own descriptor length (one slice per row: a step per panel round)
+    (20011, 128, 17, 1), (20011, 128, 33, 1), (20011, 128, 48, 1), (20011, 128, 64, 1),
+    (20011, 128, 80, 1), (20011, 128, 96, 1), (20011, 128, 33, 10), (20011, 128, 80, 10),
+    # panel / strip / slice edge cases
+    (300000, 128, 40, 1),     # several rounds per block (p_max > 1)
+    (70000, 256, 80, 1),      # two slices, rounds of six strips
+    (33, 128, 20, 1),         # three strips in the whole pool: blocks of one strip, idle waves
+    (1, 128, 17, 1),          # one row
+    (4100, 384, 50, 1),       # three slices: the 512-float fold falls behind the row's end
+    (4100, 640, 33, 4),       # five slices: one whole chunk + a quarter
+    (7001, 192, 25, 1),       # slice width 64 (dim % 128 != 0): four rows per DMA instruction
+    (7001, 64, 80, 1),
+    (7001, 320, 64, 3),
+    (2500, 1000, 72, 1),      # dim padded to 1024: staged queries
+    (640, 4096, 80, 1),       # fewer strips than waves on the chip
+])
+def test_multi_tile_scan_matches_oracle(gpu, n, d, m, k):
+    """k_scan_mq (17..80 queries per pass, the pool streamed once through LDS-DMA whatever the
+    number of query tiles; SURVEY.md 8e's gathered block of 8 robots x 10 descriptors) against the
+    C oracle, bit for bit: indices and similarity bits."""
+    rs = np.random.RandomState(n + 7 * d + m)
+    X = (rs.rand(n, d).astype(np.float32) - 0.3)
+    Q = rs.rand(m, d).astype(np.float32)
+    if n > 100:
+        X[n - 2] = X[5]        # a tie across panels resolves to the lower row
+        Q[m - 1] = X[5]
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = mt.search_batch(Q, k)
+    assert gpu.cslam_pool_scan_kernel(mt.handle).decode().startswith("k_scan_mq")
+    o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+    kk = int(o_cnt[0])
+    np.testing.assert_array_equal(rows, o_idx[:, :kk])
+    assert sims.tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    if n > 100:
+        assert rows[m - 1, 0] == 5
+    mt.close()
+
+
+def test_full_size_best_match_equals_oracle(gpu):
+    """BASELINE cfg2 at FULL size, the variant bench.py times: 100 000 x 4096, 16 queries, k = 1
+    (k_scan_dma<...,best> with the 893-wave partition that is only taken near 100k rows) - and the
+    split-window call with the split near the end - bit for bit against the C oracle on the whole
+    pool (about 2 s of CPU); then the cfg4 steady-state block of 80 gathered descriptors on the
+    same pool (k_scan_mq<T=5,...,best>)."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    from cslam_amd import _lib
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    N, D = 100_000, 4096
+    g = torch.Generator(device="cuda").manual_seed(9)
+    X = torch.rand((N, D), device="cuda", generator=g)
+    X[99_990] = X[4242]                      # a tie across the split and across waves
+    m = NearestNeighborsMatching(dim=D, capacity_hint=N)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(gpu.cslam_pool_add_dev(m.handle, ctypes.c_void_p(X.data_ptr()), N, D, ctypes.c_void_p(st)))
+    torch.cuda.synchronize()
+    m.n = N
+    Q = torch.rand((80, D), device="cuda", generator=g)
+    Q[3] = X[4242]
+    Xh, Qh = X.cpu().numpy(), Q.cpu().numpy()
+    o_idx, o_sim, _ = oracle_knn.search(Xh, Qh, 1)
+
+    def best(mq):
+        idx = torch.empty((mq, 1), dtype=torch.int32, device="cuda")
+        sim = torch.empty((mq, 1), dtype=torch.float32, device="cuda")
+        _lib.check(gpu.cslam_pool_search_dev(m.handle, ctypes.c_void_p(Q.data_ptr()), D, mq, 1,
+                                             ctypes.c_void_p(idx.data_ptr()),
+                                             ctypes.c_void_p(sim.data_ptr()), ctypes.c_void_p(st)))
+        torch.cuda.synchronize()
+        return idx.cpu().numpy()[:, 0], sim.cpu().numpy()[:, 0]
+
+    i16, s16 = best(16)
+    name = gpu.cslam_pool_scan_kernel(m.handle).decode()
+    assert name.startswith("k_scan_dma") and name.endswith("best>"), name
+    np.testing.assert_array_equal(i16, o_idx[:16, 0])
+    assert s16.tobytes() == o_sim[:16, 0].tobytes()
+    assert i16[3] == 4242
+
+    i80, s80 = best(80)
+    name = gpu.cslam_pool_scan_kernel(m.handle).decode()
+    assert name.startswith("k_scan_mq<T=5") and name.endswith("best>"), name
+    np.testing.assert_array_equal(i80, o_idx[:, 0])
+    assert s80.tobytes() == o_sim[:, 0].tobytes()
+
+    # split window (the sharded step: best OLD row, best row of the block just appended)
+    split = N - 16
+    oa_idx, oa_sim, _ = oracle_knn.search(Xh[:split], Qh, 1)
+    oc_idx, oc_sim, _ = oracle_knn.search(Xh[split:], Qh, 1)
+    for mq in (16, 80):
+        out = [torch.full((mq,), -7, dtype=torch.int32, device="cuda"), torch.zeros(mq, device="cuda"),
+               torch.full((mq,), -7, dtype=torch.int32, device="cuda"), torch.zeros(mq, device="cuda")]
+        _lib.check(gpu.cslam_pool_search_best_split_dev(
+            m.handle, ctypes.c_void_p(Q.data_ptr()), D, mq, split, -1,
+            *[ctypes.c_void_p(t.data_ptr()) for t in out], ctypes.c_void_p(st)))
+        torch.cuda.synchronize()
+        ia, sa, ic, sc = [t.cpu().numpy() for t in out]
+        np.testing.assert_array_equal(ia, oa_idx[:mq, 0])
+        np.testing.assert_array_equal(ic, oc_idx[:mq, 0] + split)
+        assert sa.tobytes() == oa_sim[:mq, 0].tobytes()
+        assert sc.tobytes() == oc_sim[:mq, 0].tobytes()
+        assert ia[3] == 4242 and ic[3] == 99_990
+    m.close()
+
+
 def test_full_size_properties(gpu):
     """BASELINE cfg2 size (100k x 4096) through size-independent properties: every sampled pool
     row retrieves itself first with similarity 1 (to 1e-6), results are sorted, a duplicated row
@@ -422,7 +532,10 @@ def test_full_size_properties(gpu):
     (40000, 256, 16, 123),        # split inside the first panel
     (3000, 256, 9, 1500),         # small pool: fewer panels than waves
     (70, 256, 16, 64),            # one strip per panel, partial last strip
-    (2500, 1024, 40, 2400),       # > 16 queries: one launch per 16
+    (2500, 1024, 40, 2400),       # > 16 queries: one k_scan_mq pass (T = 3)
+    (18000, 128, 80, 17990),      # cfg4's gathered block: 80 descriptors, one pass (T = 5)
+    (9000, 4096, 80, 8990),
+    (30000, 256, 100, 29000),     # 97..128 queries: one k_scan_dma launch per 16 (the GEMM regime for plain searches)
     (1200, 48, 7, 1000),          # dim % 64 != 0: two range searches behind the same entry point
     (18000, 128, 16, 17990),      # slice width 128
     (75, 128, 16, 70),
