@@ -1721,7 +1721,7 @@ int mq_pass_queries(int left) {
 // for the remaining tail strips (blocks of 4 strips x 1/ks of the 512-float chunks, chunk partials
 // to a scratch array) and a combine launch that folds those in chunk order (same bits).
 struct MqPlan {
-    int tiles, kw, n_blocks, p_max;
+    int tiles, kw, waves, n_blocks, p_max;
     int64_t n_main;      // rows of the main launch (all of them when there is no tail)
     int tail_groups, tail_ks, nchunks;   // K-split tail: strip groups x K parts
     int64_t tail_strips;
@@ -1732,19 +1732,23 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     static Knob k_tail{"CSLAM_MQ_TAIL", 1};
     MqPlan g{};
     g.tiles = (m + 15) / 16;
-    g.kw = p->dp % 128 == 0 ? 128 : 64;
+    static Knob k_kw{"CSLAM_MQ_KW", 0};   // A/B: force 64-float slices where 128 would do
+    g.kw = p->dp % 128 == 0 && knob(k_kw) != 64 ? 128 : 64;
+    static Knob k_waves{"CSLAM_MQ_WAVES", 4};   // A/B: 8 = two waves per SIMD (builds with -DCSLAM_MQ_WAVES8 only)
+    g.waves = knob(k_waves) == 8 && mq_waves_available(8) ? 8 : 4;
+    if (g.waves == 8) g.kw = 64;                // eight private rings fit the LDS with 4-KiB stages only
     g.nchunks = (p->dp + 511) / 512;
-    const int ns = mq_panel_strips(g.tiles);
+    const int ns = mq_panel_strips(g.tiles, g.waves);
     const int64_t strips = (p->vn + 15) / 16;
-    const int64_t want = (strips + 3) / 4;   // a strip per wave at least
+    const int64_t want = (strips + g.waves - 1) / g.waves;   // a strip per wave at least
     g.n_blocks = (int)(want < p->cus ? (want < 1 ? 1 : want) : p->cus);
     g.n_main = p->vn;
-    const int64_t waves = 4 * (int64_t)g.n_blocks;
+    const int64_t waves = (int64_t)g.waves * g.n_blocks;
     const int64_t q = strips / waves, tail = strips - q * waves;
     if (knob(k_tail) && q >= 1 && tail > 0) {
         // cost in strip times (one strip through all slices): q + 1 as one launch; with the tail
         // K-split over ks parts: q + 1/ks + the extra launches (~5 us of ~10 us per chunk)
-        const int64_t groups = (tail + 3) / 4;
+        const int64_t groups = (tail + g.waves - 1) / g.waves;
         int64_t ks = p->cus / groups;
         ks = ks < 1 ? 1 : (ks > g.nchunks ? g.nchunks : ks);
         const double part_cost = (double)((g.nchunks + ks - 1) / ks) / g.nchunks + 0.6 / g.nchunks;
@@ -1757,22 +1761,26 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     }
     const int64_t strips_main = (g.n_main + 15) / 16;
     const int64_t strips_max = (strips_main + g.n_blocks - 1) / g.n_blocks;   // blocks take whole strips
-    g.p_max = (int)((strips_max + 4 * ns - 1) / (4 * ns));
-    g.n_cand = (int64_t)g.n_blocks * g.p_max * 4 + g.tail_strips;
+    g.p_max = (int)((strips_max + g.waves * ns - 1) / (g.waves * ns));
+    g.n_cand = (int64_t)g.n_blocks * g.p_max * g.waves + g.tail_strips;
     g.nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
     return g;
 }
 const char* mq_name(const MqPlan& g, bool best) {
-    static const char* const names[2][2][4] = {
-        {{"k_scan_mq<T=2,KW=128,NST=3>", "k_scan_mq<T=3,KW=128,NST=3>", "k_scan_mq<T=4,KW=128,NST=2>",
-          "k_scan_mq<T=5,KW=128,NST=2>"},
-         {"k_scan_mq<T=2,KW=64,NST=6>", "k_scan_mq<T=3,KW=64,NST=6>", "k_scan_mq<T=4,KW=64,NST=6>",
-          "k_scan_mq<T=5,KW=64,NST=6>"}},
-        {{"k_scan_mq<T=2,KW=128,NST=3,best>", "k_scan_mq<T=3,KW=128,NST=3,best>",
-          "k_scan_mq<T=4,KW=128,NST=2,best>", "k_scan_mq<T=5,KW=128,NST=2,best>"},
-         {"k_scan_mq<T=2,KW=64,NST=6,best>", "k_scan_mq<T=3,KW=64,NST=6,best>",
-          "k_scan_mq<T=4,KW=64,NST=6,best>", "k_scan_mq<T=5,KW=64,NST=6,best>"}}};
-    return names[best ? 1 : 0][g.kw == 128 ? 0 : 1][g.tiles - 2];
+    static const char* const names[3][2][4] = {
+        {{"k_scan_mq<T=2,KW=128,NST=3,NW=4>", "k_scan_mq<T=3,KW=128,NST=3,NW=4>", "k_scan_mq<T=4,KW=128,NST=2,NW=4>",
+          "k_scan_mq<T=5,KW=128,NST=2,NW=4>"},
+         {"k_scan_mq<T=2,KW=128,NST=3,NW=4,best>", "k_scan_mq<T=3,KW=128,NST=3,NW=4,best>",
+          "k_scan_mq<T=4,KW=128,NST=2,NW=4,best>", "k_scan_mq<T=5,KW=128,NST=2,NW=4,best>"}},
+        {{"k_scan_mq<T=2,KW=64,NST=6,NW=4>", "k_scan_mq<T=3,KW=64,NST=6,NW=4>", "k_scan_mq<T=4,KW=64,NST=6,NW=4>",
+          "k_scan_mq<T=5,KW=64,NST=6,NW=4>"},
+         {"k_scan_mq<T=2,KW=64,NST=6,NW=4,best>", "k_scan_mq<T=3,KW=64,NST=6,NW=4,best>",
+          "k_scan_mq<T=4,KW=64,NST=6,NW=4,best>", "k_scan_mq<T=5,KW=64,NST=6,NW=4,best>"}},
+        {{"k_scan_mq<T=2,KW=64,NST=4,NW=8>", "k_scan_mq<T=3,KW=64,NST=3,NW=8>", "k_scan_mq<T=4,KW=64,NST=3,NW=8>",
+          "k_scan_mq<T=5,KW=64,NST=3,NW=8>"},
+         {"k_scan_mq<T=2,KW=64,NST=4,NW=8,best>", "k_scan_mq<T=3,KW=64,NST=3,NW=8,best>",
+          "k_scan_mq<T=4,KW=64,NST=3,NW=8,best>", "k_scan_mq<T=5,KW=64,NST=3,NW=8,best>"}}};
+    return names[g.waves == 8 ? 2 : (g.kw == 128 ? 0 : 1)][best ? 1 : 0][g.tiles - 2];
 }
 // stage `m` queries (17..80) and scan the window [v0, v0 + vn): raw dots, or (best) one composite
 // per query and panel in cand (and cand_c behind `split`, window-relative, when given)
@@ -1807,7 +1815,7 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         CSLAM_TRY(p->part.reserve((size_t)g.tail_strips * g.nchunks * g.tiles * 64 * sizeof(f32x4)));
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    CSLAM_TRY(launch_scan_mq(a, g.tiles, g.kw, best ? kMqModeBest : kMqModeDots, g.nt, st));
+    CSLAM_TRY(launch_scan_mq(a, g.tiles, g.kw, g.waves, best ? kMqModeBest : kMqModeDots, g.nt, st));
     if (g.tail_strips > 0) {
         // the tail window [n_main, vn): K-split launch, then the fold + epilogue of its strips
         MqArgs b = a;
@@ -1821,8 +1829,8 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         b.p_max = 1;
         b.part = p->part.as<f32x4>();
         b.part_ks = g.tail_ks;
-        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.kw, kMqModePart, false, st));
-        CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * 4, st));
+        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.kw, g.waves, kMqModePart, false, st));
+        CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * g.waves, st));
     }
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
@@ -1851,8 +1859,8 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
     // exactly (128), the GEMM beyond.
     const bool mq = mq_scan_applies(p, m);
     auto scan_cost = [mq](int mm) {
-        if (mq) {   // balanced passes of <= 80 queries on k_scan_mq (profiles/r03_m_sweep.txt)
-            static const double tile_cost[6] = {0.0, 1.0, 1.2, 1.5, 1.75, 2.1};
+        if (mq) {   // balanced passes of <= 80 queries on k_scan_mq (profiles/r03_mq_time.txt)
+            static const double tile_cost[6] = {0.0, 1.0, 1.17, 1.44, 1.72, 2.07};
             double c = 0.0;
             for (int left = mm; left > 0;) {
                 const int mb = mq_pass_queries(left);
@@ -1870,7 +1878,9 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
     // (1.85) for 33..64 queries, 13 % better for 129..192 (1.51 vs 1.74 ms at 192)
     static const int gemm64_env = getenv("CSLAM_GEMM64") ? atoi(getenv("CSLAM_GEMM64")) : 1;
     const bool narrow = gemm64_env && gemm_env != 32 && gemm_env != 4 && m > 128 && m <= 192;
-    const double gemm_cost = narrow ? 1.61 * ((m + 63) / 64) : 3.2 * ((m + 127) / 128);
+    // a 128-query GEMM tile pass costs 3.05 units where the tiles fill whole waves of the chip (1024
+    // queries: 124 TFLOP/s), 3.7 for one or two tiles (128 queries x 100k rows: 782 tiles on 512 slots)
+    const double gemm_cost = narrow ? 1.8 * ((m + 63) / 64) : (m >= 384 ? 3.05 : 3.7) * ((m + 127) / 128);
     const bool use_gemm = gemm_env && m >= 96 && p->vn > 0 && gemm_cost < scan_cost(m);
     if (use_gemm) {
         // MFMA-bound regime: stage the whole chunk once (padded to whole query tiles), one GEMM
@@ -2126,8 +2136,9 @@ int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_
 // per query and panel), then k_best_pair per pass - no dots round trip.  Both windows of a split
 // search (rows before / from `split`, window-relative) in the same pass.
 bool mq_best_applies(const cslam_pool* p, int m) {
-    // beyond two passes the 128-query GEMM tiles win (cost model in compute_dots)
-    return mq_scan_applies(p, m) && m <= 2 * 16 * mq_max_tiles() && (m <= 96 || m > 128);
+    // up to four passes: beyond that the 128-query GEMM tiles win even with their dots round trip and
+    // select launches (cost model in compute_dots)
+    return mq_scan_applies(p, m) && m <= 4 * 16 * mq_max_tiles();
 }
 int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
                  int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {

@@ -29,6 +29,9 @@
 // (+ the split window of csrc/shard.hip); MODE_PART: the block multiplies only the 512-float
 // chunks [chunk_lo, chunk_hi) of its rows and leaves every chunk's partial in a scratch array -
 // the K-split tail / small-pool pass, folded in chunk order by k_mq_combine (same bits).
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 #include "composite.hpp"
 #include "dma_scan.hpp"
@@ -40,14 +43,22 @@ namespace {
 
 constexpr int MODE_DOTS = 0, MODE_BEST = 1, MODE_PART = 2;
 
-template <int T, int KW, int NST, int NS, int AUX, int MODE>
-__global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant
+// expression in the body (the scheduling builtins take nothing else)
+template <int... I, class F>
+__device__ inline void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece;
     constexpr int NP = 16 / R;            // DMA pieces per 16-row stage (== NB)
     constexpr int kStage = NP * kPiece;   // 16 rows x KW floats
     constexpr int kFold = 512 / KW;       // slices per 512-float chunk
-    constexpr int NBP = T * NP / 4;       // B pieces per wave and slice
+    constexpr int NBP = T * NP / NW;      // B pieces per wave and slice (at least: wave w takes pieces w, w + NW, ...)
+    constexpr int NBPX = (T * NP + NW - 1) / NW;
     constexpr int RV = MODE == MODE_BEST ? 2 : 0;   // row-norm loads per step
     // The refill of a slot (stage j + NST into stage j's slot) is issued behind the k-blocks of
     // stage j, PPK pieces per k-block; in front of k-block WP the NEXT stage must have landed and
@@ -57,13 +68,20 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
     constexpr int PPK = NST == 2 ? 2 : 1;
     constexpr int WP = NB - 2;
     constexpr int kIssuedAtWP = PPK * WP < NP ? PPK * WP : NP;
-    static_assert(NP == NB && (T * NP) % 4 == 0 && NB >= 4, "geometry");
+    // B pieces every wave issues in front of k-block WP of a step's first stage (piece x goes behind
+    // chain PPK + x / NB of k-block x % NB): pieces x < NBP with x % NB < WP
+    constexpr int kBBeforeWP = (NBP / NB) * WP + ((NBP % NB) < WP ? (NBP % NB) : WP);
+    // ... and behind the last X piece of that stage's refill (k-block kLastX; B slots follow the X slots)
+    constexpr int kLastX = (NP + PPK - 1) / PPK - 1;
+    constexpr int kBAfterX = (NBP / NB) * (NB - kLastX) + ((NBP % NB) > kLastX ? (NBP % NB) - kLastX : 0);
+    constexpr bool PF = NW == 4;          // B fragments of the next k-block prefetched into a second register set
+    static_assert(NP == NB && NB >= 4 && (NW == 4 || NW == 8), "geometry");
     extern __shared__ __attribute__((aligned(16))) char mq_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     char* ring = mq_lds + wave * NST * kStage;
-    char* bbuf = mq_lds + 4 * NST * kStage;   // [2][T][kStage]
+    char* bbuf = mq_lds + NW * NST * kStage;   // [2][T][kStage]
     const int nkc_all = A.dp / KW;
     // MODE_PART (K-split launch): grid = n_blocks strip groups x part_ks K parts; this block multiplies
     // the whole 512-float chunks [chunk_lo, chunk_hi) of its rows only
@@ -84,13 +102,13 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
     const int64_t bs_lo = (int64_t)bidx * bq + (bidx < brem ? bidx : brem);
     const int bs = (int)(bq + (bidx < brem ? 1 : 0));   // strips of this block
     if (bs == 0 || nkc <= 0) return;   // block-uniform
-    const int P = (bs + 4 * NS - 1) / (4 * NS);
-    const int npan = 4 * P;
+    const int P = (bs + NW * NS - 1) / (NW * NS);
+    const int npan = NW * P;
     const int pq = bs / npan, prem = bs - pq * npan;
     auto panel_s0 = [&](int q) { return bs_lo + (int64_t)q * pq + (q < prem ? q : prem); };   // first strip
     auto panel_lo = [&](int q) { return panel_s0(q) << 4; };
     auto panel_rows = [&](int rd) {
-        const int q = 4 * rd + wave;
+        const int q = NW * rd + wave;
         const int64_t lo = panel_lo(q);
         int64_t hi = panel_lo(q + 1);
         hi = hi < A.n ? hi : A.n;
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
             if (rows > 0) {
                 i_ns = (rows + 15) >> 4;
                 i_last = rows - 1;
-                i_base = reinterpret_cast<const char*>(A.X + panel_lo(4 * i_rd + wave) * A.xs + (int64_t)kc_begin * KW);
+                i_base = reinterpret_cast<const char*>(A.X + panel_lo(NW * i_rd + wave) * A.xs + (int64_t)kc_begin * KW);
                 break;
             }
             ++i_rd;
@@ -167,18 +185,22 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
         ++i_rd;
         i_panel();
     };
-    // this wave's quarter of the B pieces of slice kc -> buffer bb
-    auto issue_b = [&](int kc, int bb) {
-#pragma unroll
-        for (int x = 0; x < NBP; ++x) {
-            const int pi = wave * NBP + x;          // piece of the slice: tile pi / NP, piece pi % NP
+    // this wave's share of the B pieces of slice kc -> buffer bb: pieces wave, wave + NW, ... of the
+    // slice's T NP (piece pi = tile pi / NP, piece pi % NP of the tile)
+    auto issue_b_piece = [&](int x, int kc, int bb) {
+        const int pi = wave + NW * x;
+        if (pi < T * NP) {   // wave-uniform
             const int t = pi / NP, pp = pi % NP;
             const float* a = A.Q + (int64_t)(16 * t + R * pp + sub) * A.dp + (kc_begin + kc) * KW + seg * 4;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)a,
                 (__attribute__((address_space(3))) void*)(bbuf + (bb * T + t) * kStage + pp * kPiece), 16, 0, 0);
+            ++issued;
         }
-        issued += NBP;
+    };
+    auto issue_b = [&](int kc, int bb) {
+#pragma unroll
+        for (int x = 0; x < NBPX; ++x) issue_b_piece(x, kc, bb);
         mark_b = issued;
     };
 
@@ -212,9 +234,13 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
 
     int slot = 0;      // ring slot of the stage the consumer is at
     int gstep = 0;
+#if defined(CSLAM_MQ_PROBE_CLOCK)   // timing probe: shader clock held inside the stage loop
+    const uint64_t pc_t0 = __builtin_amdgcn_s_memtime(), pc_r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t pc_wait_b = 0, pc_wait_bar = 0;
+#endif
     for (int rd = 0; rd < P; ++rd) {
         const int rows = panel_rows(rd);
-        const int64_t lo = panel_lo(4 * rd + wave);
+        const int64_t lo = panel_lo(NW * rd + wave);
         const int ns = (rows + 15) >> 4;
         f32x4 acc[NS][T], tot[NS][T];
 #pragma unroll
@@ -232,9 +258,19 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
             const int bb = gstep & 1;
             // my B pieces of this slice have landed ... and so have everybody's; everybody is also
             // done with the other buffer (slice kc - 1)
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+            const uint64_t pc_b0 = __builtin_amdgcn_s_memtime();
+#endif
             wait_vm_dyn(issued - mark_b);
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+            const uint64_t pc_b1 = __builtin_amdgcn_s_memtime();
+#endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+            pc_wait_b += pc_b1 - pc_b0;
+            pc_wait_bar += __builtin_amdgcn_s_memtime() - pc_b1;
+#endif
             if (MODE == MODE_BEST) {
                 // 1/||x|| of the panel's <= 128 rows for the epilogue, lane l rows lo + l and
                 // lo + 64 + l (clamped into the window).  Issued at EVERY step, unconditionally (an
@@ -248,8 +284,11 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
                 issued += 2;
                 mark_rv = issued;
             }
-            // slice kc + 1 (slice 0 again behind the last one: the next round's first, or nobody's)
-            issue_b(kc + 1 == nkc ? 0 : kc + 1, bb ^ 1);
+            // slice kc + 1 (slice 0 again behind the last one: the next round's first, or nobody's) is
+            // requested piece by piece between the chains of this step's FIRST stage (a burst of
+            // DMA issues at the top of the step kept the matrix pipe idle ~600 clocks per step)
+            const int kc_nx = kc + 1 == nkc ? 0 : kc + 1;
+            if (ns == 0) issue_b(kc_nx, bb ^ 1);
             const char* bs = bbuf + bb * T * kStage + rd_off;
             // end of a 512-float chunk / of the row: fold (or, MODE_PART, hand the partial over)
             const bool fold = (((kc_begin + kc + 1) & (kFold - 1)) == 0) || kc_begin + kc + 1 == nkc_all;
@@ -263,43 +302,90 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
                     // order, so every read of the slot has returned before anything overwrites it.
                     const int nslot = slot + 1 == NST ? 0 : slot + 1;
                     const char* nx = ring + nslot * kStage + rd_off;
-                    if (s == 0) {
+                    if (PF && s == 0) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage);
                     }
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) {
+                    static_for(std::make_integer_sequence<int, NB>{}, [&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
                         // B fragments of the next k-block (of k-block 0 behind the last: the next
                         // strip of this step starts with them)
                         f32x4 bnx[T];
+                        if (!PF) {   // two waves per SIMD: the partner's MFMAs cover this wave's LDS latency
 #pragma unroll
-                        for (int t = 0; t < T; ++t)
-                            bnx[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage + (i + 1 < NB ? i + 1 : 0) * 64);
+                            for (int t = 0; t < T; ++t)
+                                bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage + i * 64);
+                        }
                         if (i == WP) {
                             // The next stage has landed.  Younger than its last piece: the stages
-                            // behind it in the ring, this stage's refill so far, and the step-top
-                            // operations when a step began since (at least then: fewer strips per
-                            // step only make the count an under-estimate, i.e. a longer wait).
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP + kIssuedAtWP + (s <= NST - 2 ? NBP + RV : 0))
+                            // behind it in the ring, this stage's refill so far, and what a step's top
+                            // and first stage add (row norms, B pieces) when they lie in between.  Every
+                            // term is what EVERY wave has certainly issued: fewer strips per step only
+                            // make the count an under-estimate, i.e. a longer wait - but an
+                            // under-estimate that reaches into the pieces just requested is a stall of a
+                            // whole memory round trip, so the terms are exact for full steps.
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP + kIssuedAtWP +
+                                                                    (s == 0 ? RV + kBBeforeWP
+                                                                            : (s <= NST - 2 ? RV + NBP : (s == NST - 1 ? kBAfterX : 0))))
                                          : "memory");
 #pragma unroll
                             for (int i2 = 0; i2 < WP; ++i2)
                                 a[i2] = *reinterpret_cast<const f32x4*>(nx + i2 * 64);
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int t = 0; t < T; ++t)
-                                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bcur[t][j], acc[s][t], 0, 0, 0);
-                        if (i >= WP) a[i] = *reinterpret_cast<const f32x4*>(nx + i * 64);
-#pragma unroll
-                        for (int x = 0; x < PPK; ++x)
-                            if (PPK * i + x < NP) issue_piece(PPK * i + x, slot);
+                        // Order of the k-block, pinned by scheduling barriers: the LDS reads first, then
+                        // ONE TILE AFTER THE OTHER - four MFMAs in a row on the same accumulator.  The
+                        // matrix pipe forwards the accumulator between back-to-back MFMAs of one chain
+                        // (32 clocks each); every change of accumulator costs ~8 clocks more: round-robin
+                        // over the tiles, which is what the compiler's scheduler makes of independent
+                        // chains, ran at 40 clocks per MFMA (tools/mfma_rate2.hip,
+                        // profiles/r03_mfma_rate2.txt: 38.1 round-robin, 34.1 in runs of four, one wave
+                        // per SIMD).  Same chains, same order inside each: same bits.
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
-                    }
+                        for (int t = 0; t < T; ++t) {
+#if defined(CSLAM_MQ_PROBE_NO_MFMA)   // timing probe (tools/build_mq_probes.sh): operands consumed, no matrix work
+                            asm volatile("" ::"v"(a[i]), "v"(bcur[t]));
+#else
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bcur[t][j], acc[s][t], 0, 0, 0);
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (PF && t == 0) {
+                                // The next k-block's B fragments, requested BEHIND the first chain: hipcc
+                                // waits lgkmcnt(0) in front of a k-block whenever an LDS-DMA was issued
+                                // since the last wait (it cannot count LDS reads past one), so reads
+                                // requested in front of that wait would be waited for on the spot -
+                                // ~120 clocks of LDS latency per k-block, 40 clocks per MFMA instead of 34.
+#pragma unroll
+                                for (int t2 = 0; t2 < T; ++t2)
+                                    bnx[t2] = *reinterpret_cast<const f32x4*>(bs + t2 * kStage + (i + 1 < NB ? i + 1 : 0) * 64);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#if !defined(CSLAM_MQ_PROBE_NO_DMA)    // timing probe: the ring is never refilled (wrong results)
+                            // the refill's DMA issues between the first chains of the k-block
+                            if (t < PPK && PPK * i + t < NP) {
+                                issue_piece(PPK * i + t, slot);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#endif
+                            // ... and, in the step's first stage, the next slice's B pieces behind the others
+                            if (s == 0 && t >= PPK && i + NB * (t - PPK) < NBPX) {
+                                issue_b_piece(i + NB * (t - PPK), kc_nx, bb ^ 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        if (i >= WP) {
+                            a[i] = *reinterpret_cast<const f32x4*>(nx + i * 64);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (PF) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
+                        }
+                    });
                     issued += NP;
+                    if (s == 0) mark_b = issued;   // an upper bound of the last B piece's position: a longer wait at worst
                     i_advance();
 #pragma unroll
                     for (int t = 0; t < T; ++t) asm volatile("" : "+a"(acc[s][t]));
@@ -380,7 +466,7 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
                 }
             }
             // one composite per query and panel; a panel without rows leaves the empty composite
-            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * 4 + wave;
+            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * NW + wave;
             if (g == 0) {
 #pragma unroll
                 for (int t = 0; t < T; ++t)
@@ -408,9 +494,19 @@ __global__ __launch_bounds__(256) void k_scan_mq(const MqArgs A) {
             }
         }
     }
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+    {
+        const uint64_t dt = __builtin_amdgcn_s_memtime() - pc_t0, dr = __builtin_amdgcn_s_memrealtime() - pc_r0;
+        if ((blockIdx.x == 3 || blockIdx.x == 100) && threadIdx.x == 0 && MODE != MODE_PART)
+            printf("mq clock probe: block %d T=%d NW=%d: %llu shader cycles in %llu x 10 ns = %.3f GHz, %.1f cycles per MFMA; "
+                   "of them waiting for B %llu, at the barrier %llu (%d steps)\n",
+                   (int)blockIdx.x, T, NW, (unsigned long long)dt, (unsigned long long)dr, (double)dt / (10.0 * dr),
+                   (double)dt / ((double)J * NB * 4 * T), (unsigned long long)pc_wait_b, (unsigned long long)pc_wait_bar, gstep);
+    }
+#endif
     if (MODE == MODE_BEST && g == 0) {   // rounds this block does not have (blocks differ by one row)
         for (int rd = P; rd < A.p_max; ++rd) {
-            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * 4 + wave;
+            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * NW + wave;
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (16 * t + r < A.m_valid) {
@@ -502,60 +598,87 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
 }
 
 // LDS bytes of a variant
-template <int T, int KW, int NST>
+template <int T, int KW, int NST, int NW>
 constexpr size_t mq_lds_bytes() {
-    return (size_t)(4 * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece;
+    return (size_t)(NW * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece;
 }
 
-template <int T, int KW, int NST, int NS, int AUX, int MODE>
+template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
 int launch_one(const MqArgs& a, hipStream_t st) {
-    constexpr size_t lds = mq_lds_bytes<T, KW, NST>();
+    constexpr size_t lds = mq_lds_bytes<T, KW, NST, NW>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};
     if (!attr_set[a.device & 63]) {
-        CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_mq<T, KW, NST, NS, AUX, MODE>,
+        CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_mq<T, KW, NST, NS, AUX, MODE, NW>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[a.device & 63] = true;
     }
     const unsigned grid = (unsigned)a.n_blocks * (MODE == MODE_PART ? (unsigned)a.part_ks : 1u);
-    hipLaunchKernelGGL((k_scan_mq<T, KW, NST, NS, AUX, MODE>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_scan_mq<T, KW, NST, NS, AUX, MODE, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
 
-template <int T, int KW, int NST, int NS>
+template <int T, int KW, int NST, int NS, int NW>
 int launch_mode(const MqArgs& a, int mode, bool nt, hipStream_t st) {
-    if (mode == MODE_PART) return launch_one<T, KW, NST, NS, 0, MODE_PART>(a, st);
+    if (mode == MODE_PART) return launch_one<T, KW, NST, NS, 0, MODE_PART, NW>(a, st);
     if (mode == MODE_BEST)
-        return nt ? launch_one<T, KW, NST, NS, 2, MODE_BEST>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_BEST>(a, st);
-    return nt ? launch_one<T, KW, NST, NS, 2, MODE_DOTS>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_DOTS>(a, st);
+        return nt ? launch_one<T, KW, NST, NS, 2, MODE_BEST, NW>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_BEST, NW>(a, st);
+    return nt ? launch_one<T, KW, NST, NS, 2, MODE_DOTS, NW>(a, st) : launch_one<T, KW, NST, NS, 0, MODE_DOTS, NW>(a, st);
 }
 
 }  // namespace
 
 namespace cslam {
 
+// Variants.  Four waves per block (one per SIMD), 128-float slices where the row length allows, is
+// what ships.  The eight-wave form (two per SIMD, eight private rings of 4-KiB stages: 64-float
+// slices, which stream as fast as 128-float ones - profiles/r03_mq_probes.txt) is the same template
+// with NW = 8; measured equal or slightly slower at every tile count once the MFMAs run in chains
+// (0.567 vs 0.560 ms for 80 queries x 100k x 4096-d, 0.322 vs 0.310 for 32), so it is only
+// compiled with -DCSLAM_MQ_WAVES8 (CSLAM_MQ_WAVES=8 then selects it, A/B runs).
 int mq_max_tiles() { return 5; }
-int mq_panel_strips(int tiles) { return tiles >= 5 ? 6 : 8; }
+int mq_waves_available(int waves) {
+#if defined(CSLAM_MQ_WAVES8)
+    return waves == 8 || waves == 4;
+#else
+    return waves == 4;
+#endif
+}
+int mq_panel_strips(int tiles, int waves) {
+    if (waves == 8) return tiles >= 5 ? 3 : (tiles == 4 ? 4 : (tiles == 3 ? 5 : 8));
+    return tiles >= 4 ? 6 : 8;   // acc + tot = 8 NS T AccVGPRs of 256: eight strips up to three tiles, six beyond
+}
 
-int launch_scan_mq(const MqArgs& a, int tiles, int kw, int mode, bool nt, hipStream_t st) {
+int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool nt, hipStream_t st) {
     if (mode == kMqModePart && a.part_ks < 1) return fail(CSLAM_E_INVALID, "scan_mq: K parts");
-    if (tiles < 2 || tiles > 5 || (kw != 128 && kw != 64) || a.dp % kw != 0 || a.n <= 0 || a.n_blocks < 1)
-        return fail(CSLAM_E_INVALID, "scan_mq: bad launch (tiles %d, slice %d, rows %lld)", tiles, kw,
-                    (long long)a.n);
+    if (tiles < 2 || tiles > 5 || (kw != 128 && kw != 64) || a.dp % kw != 0 || a.n <= 0 || a.n_blocks < 1 ||
+        !mq_waves_available(waves) || (waves == 8 && kw != 64))
+        return fail(CSLAM_E_INVALID, "scan_mq: bad launch (tiles %d, slice %d, waves %d, rows %lld)", tiles, kw,
+                    waves, (long long)a.n);
+#if defined(CSLAM_MQ_WAVES8)
+    if (waves == 8) {
+        switch (tiles) {
+            case 2: return launch_mode<2, 64, 4, 8, 8>(a, mode, nt, st);
+            case 3: return launch_mode<3, 64, 3, 5, 8>(a, mode, nt, st);
+            case 4: return launch_mode<4, 64, 3, 4, 8>(a, mode, nt, st);
+            default: return launch_mode<5, 64, 3, 3, 8>(a, mode, nt, st);
+        }
+    }
+#endif
     if (kw == 128) {
         switch (tiles) {
-            case 2: return launch_mode<2, 128, 3, 8>(a, mode, nt, st);
-            case 3: return launch_mode<3, 128, 3, 8>(a, mode, nt, st);
-            case 4: return launch_mode<4, 128, 2, 8>(a, mode, nt, st);
-            default: return launch_mode<5, 128, 2, 6>(a, mode, nt, st);
+            case 2: return launch_mode<2, 128, 3, 8, 4>(a, mode, nt, st);
+            case 3: return launch_mode<3, 128, 3, 8, 4>(a, mode, nt, st);
+            case 4: return launch_mode<4, 128, 2, 6, 4>(a, mode, nt, st);
+            default: return launch_mode<5, 128, 2, 6, 4>(a, mode, nt, st);
         }
     }
     switch (tiles) {
-        case 2: return launch_mode<2, 64, 6, 8>(a, mode, nt, st);
-        case 3: return launch_mode<3, 64, 6, 8>(a, mode, nt, st);
-        case 4: return launch_mode<4, 64, 6, 8>(a, mode, nt, st);
-        default: return launch_mode<5, 64, 6, 6>(a, mode, nt, st);
+        case 2: return launch_mode<2, 64, 6, 8, 4>(a, mode, nt, st);
+        case 3: return launch_mode<3, 64, 6, 8, 4>(a, mode, nt, st);
+        case 4: return launch_mode<4, 64, 6, 6, 4>(a, mode, nt, st);
+        default: return launch_mode<5, 64, 6, 6, 4>(a, mode, nt, st);
     }
 }
 

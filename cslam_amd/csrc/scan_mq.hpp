@@ -23,7 +23,7 @@ struct MqArgs {
     int device;
     const float* rnx;      // 1 / ||x|| of the window's rows (best-match mode)
     uint32_t row0;         // pool row of the window's first row
-    uint64_t* cand;        // best-match mode: [m][cand_stride] composites, n_blocks * p_max * 4 per query
+    uint64_t* cand;        // best-match mode: [m][cand_stride] composites, n_blocks * p_max * waves per query
     int64_t cand_stride;
     int64_t split;         // window-relative row from which composites go to cand_c (INT64_MAX: one window)
     uint64_t* cand_c;
@@ -33,9 +33,10 @@ struct MqArgs {
 
 constexpr int kMqModeDots = 0, kMqModeBest = 1, kMqModePart = 2;
 
-int mq_max_tiles();                 // query tiles (of 16) one pass takes
-int mq_panel_strips(int tiles);     // strips (of 16 rows) per wave and round
-int launch_scan_mq(const MqArgs& a, int tiles, int kw, int mode, bool nt, hipStream_t st);
+int mq_max_tiles();                          // query tiles (of 16) one pass takes
+int mq_waves_available(int waves);            // 4 always; 8 only in builds with -DCSLAM_MQ_WAVES8
+int mq_panel_strips(int tiles, int waves);   // strips (of 16 rows) per wave and round
+int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool nt, hipStream_t st);
 // fold the K-split pass's chunk partials of window `a` (dots, or composites at cand[..][cand_off + strip])
 int launch_mq_combine(const MqArgs& a, int tiles, int nchunks, bool best, int64_t cand_off, hipStream_t st);
 

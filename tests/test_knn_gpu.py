@@ -535,7 +535,7 @@ def test_full_size_properties(gpu):
     (2500, 1024, 40, 2400),       # > 16 queries: one k_scan_mq pass (T = 3)
     (18000, 128, 80, 17990),      # cfg4's gathered block: 80 descriptors, one pass (T = 5)
     (9000, 4096, 80, 8990),
-    (30000, 256, 100, 29000),     # 97..128 queries: one k_scan_dma launch per 16 (the GEMM regime for plain searches)
+    (30000, 256, 100, 29000),     # two balanced passes of 64 (T = 4)
     (1200, 48, 7, 1000),          # dim % 64 != 0: two range searches behind the same entry point
     (18000, 128, 16, 17990),      # slice width 128
     (75, 128, 16, 70),

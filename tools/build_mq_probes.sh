@@ -1,0 +1,18 @@
+#!/bin/bash
+# Timing probes of k_scan_mq: the library with one ingredient of the stage loop compiled out
+# (results are wrong; time only).  Output: tools/probe_libs/libcslam_hip_<name>.so, loaded by
+# tools/mq_time.py through CSLAM_PROBE_LIB.
+set -e
+cd "$(dirname "$0")/../cslam_amd/csrc"
+make -j4 >/dev/null
+mkdir -p ../../tools/probe_libs build/probe
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math"
+for v in ${PROBES:-NO_DMA NO_MFMA CLOCK}; do
+  /opt/rocm/bin/hipcc $FLAGS -DCSLAM_MQ_PROBE_$v -c scan_mq.hip -o build/probe/scan_mq_$v.o &
+done
+wait
+for v in ${PROBES:-NO_DMA NO_MFMA CLOCK}; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe_libs/libcslam_hip_$v.so \
+     build/common.o build/knn.o build/probe/scan_mq_$v.o build/mac.o build/geom.o build/comm.o build/shard.o -ldl
+done
+ls -la ../../tools/probe_libs

@@ -6,14 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cslam_amd import _lib
 from cslam_amd.nns_matching import NearestNeighborsMatching
+if os.environ.get('CSLAM_PROBE_LIB'): _lib.LIB_PATH = os.environ['CSLAM_PROBE_LIB']
 L = _lib.load(); D = 4096
+MS = [int(x) for x in os.environ.get('MQ_M', '16,32,48,64,80,96,128,160').split(',')]
 sizes = [int(a) for a in sys.argv[1:]] or [100000, 25000]
 g = torch.Generator(device="cuda").manual_seed(0)
 for N in sizes:
     X = torch.rand((N, D), device="cuda", generator=g)
     m = NearestNeighborsMatching(dim=D, capacity_hint=N)
     m.add_items_device(X.data_ptr(), N, D, items=None, stream=None)
-    for M in (16, 32, 48, 64, 80, 96, 128, 160):
+    for M in MS:
         Q = torch.rand((M, D), device="cuda", generator=g)
         idx = torch.empty((M, 1), dtype=torch.int32, device="cuda"); sim = torch.empty((M, 1), dtype=torch.float32, device="cuda")
         def run():
