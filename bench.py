@@ -12,14 +12,24 @@ Workload (configs[1], fits one GPU): every rank is one robot holding a resident 
           in the pool: one HBM-bound scan + exact top-1.  value = 16 / step time.
   N > 1   one step = the sharded protocol of SURVEY.md §8e through the C ABI
           (cslam_amd.multi_robot.DeviceShard → csrc/shard.hip, csrc/comm.hip): every rank
-          publishes 16/N new descriptors, RCCL all-gather of the blocks, the own block is
-          appended to the pool, ONE scan launch of the pool for all 16 gathered descriptors (best
-          old row and best row of the new block: inter-robot match, lcsm.py:58-76 / 37-56;
+          publishes 16/N new descriptors, ONE RCCL all-gather of the blocks + keyframe ids, the own
+          block is appended to the pool, ONE scan launch of the pool for all 16 gathered descriptors
+          (best old row and best row of the new block: inter-robot match, lcsm.py:58-76 / 37-56;
           intra-robot matching off as in the node's defaults, CSLAM_BENCH_INTRA=1 turns it on),
-          20-byte match records built on the device, RCCL all-gather of the records, records
-          fetched by the host.  16 best-match evaluations per rank per step, per-GPU work fixed
-          as N grows (weak scaling): value = N * 16 / step time.  The exchange of step t+1 is
-          issued before the scan of step t (different streams), records are fetched one step late.
+          20-byte match records built on the device, ONE RCCL all-gather of the records, records
+          fetched by the host.  Per-GPU work fixed as N grows (weak scaling): 16 descriptors scanned
+          per rank and step, of which the 16 (N-1)/N FOREIGN ones are inter-robot best-match
+          evaluations (the own ones are skipped by the record kernel): value = N * 16 (N-1)/N /
+          step time (all 16 count with CSLAM_BENCH_INTRA=1).  The exchange of step t+1 is issued
+          before the scan of step t, records are fetched one step late.  Control plane (barriers,
+          max over ranks, communicator id): a gloo process group; the only GPU collectives are the
+          library's own RCCL communicator (ONE, shared by both exchanges).
+
+  --workload cfg4   BASELINE configs[3]'s own shape: 25 000 keyframes x 4096-d per robot, every robot
+          publishes 10 descriptors per step (frontend.detection_publication_max_elems_per_msg), all
+          R x 10 gathered descriptors are matched against the pool (k_scan_mq: one pass, split
+          window).  N = 1: robot 0 of 8 over the loopback communicator (80 gathered, 70 foreign);
+          N > 1: R = N over RCCL.  The default N = 1 line above is unchanged by this option.
 
 `python bench.py --gpus N` launches its own N ranks (children started before anything touches
 the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one
@@ -48,6 +58,7 @@ N_KEYFRAMES = 100_000
 DIM = 4096
 BATCH = 16
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6290 measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md:42 (fp32-input MFMA, dense)
 METRIC = "loop-closure candidates/sec (kNN+MAC), 100k keyframes x 4096-d; Fiedler-solve ms"
 
 
@@ -58,6 +69,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--keyframes", type=int, default=N_KEYFRAMES)
     ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -141,23 +153,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # Control plane only (barrier, max over ranks, the communicator id): gloo over TCP.  The
+        # GPU collectives are the library's own RCCL communicator - no torch NCCL group shares the
+        # device with the scan, one sequence of collectives per rank.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     L = _lib.load()
+    cfg4 = args.workload == "cfg4"
     N, D = args.keyframes, args.dim
-    per_rank = max(1, BATCH // world)
-    gathered_rows = per_rank * world
+    if cfg4 and args.keyframes == N_KEYFRAMES:
+        N = 25_000
+    nb_robots = world if world > 1 else (8 if cfg4 else 1)      # cfg4 at N = 1: robot 0 of 8, loopback
+    per_rank = 10 if cfg4 else max(1, BATCH // world)
+    gathered_rows = per_rank * nb_robots
     total_steps = args.warmup + args.steps
 
     # ---- resident pool (robot = rank) -------------------------------------------------------
     g = torch.Generator(device=dev).manual_seed(rank)
     X = torch.rand((N, D), device=dev, generator=g)
     X /= X.norm(dim=1, keepdim=True)
-    grow = (total_steps + 80) * per_rank if world > 1 else 0
+    grow = (total_steps + 80) * per_rank if nb_robots > 1 else 0
     pool = NearestNeighborsMatching(dim=D, device_id=local_rank, capacity_hint=N + grow)
     stream = torch.cuda.current_stream().cuda_stream
     pool.add_items_device(X.data_ptr(), N, D, items=None, stream=stream)
@@ -175,37 +191,31 @@ def main():
 
     dist_info = None
     state = {"published": 0, "matched": 0, "fetched": 0, "records": 0}
-    if world == 1:
+    intra = os.environ.get("CSLAM_BENCH_INTRA") == "1"
+    if nb_robots == 1:
         def step(t):
             search(new_local, 1, out_idx, out_sim)
 
         def drain():
             pass
     else:
-        from cslam_amd.multi_robot import (CallbackComm, DeviceShard, RcclComm,
+        from cslam_amd.multi_robot import (CallbackComm, DeviceShard, LoopbackComm, RcclComm,
                                            torch_dist_transport)
-        if backend == "nccl":
-            # two RCCL communicators (descriptor and record exchange overlap each other); their
-            # ids travel over the process group
-            ids = torch.zeros((2, _lib.CSLAM_COMM_ID_BYTES), dtype=torch.uint8, device=dev)
-            if rank == 0:
-                for i in range(2):
-                    ids[i] = torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8).to(dev)
-            dist.broadcast(ids, 0)
-            ids_h = ids.cpu().numpy()
-            comm_d = RcclComm(rank, world, ids_h[0].tobytes(), local_rank)
-            comm_r = RcclComm(rank, world, ids_h[1].tobytes(), local_rank)
+        if world == 1:
+            comm = LoopbackComm(0, nb_robots, local_rank)       # cfg4 on one GPU: compute side of the step
+        elif backend == "nccl":
+            # ONE RCCL communicator for both exchanges; its id travels over the gloo group
+            ids = [RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = RcclComm(rank, world, ids[0], local_rank)
         else:
-            name = f"{backend} through host memory (one-GPU rehearsal)"
-            comm_d = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
-            comm_r = CallbackComm(rank, world, local_rank, torch_dist_transport(), name=name)
+            comm = CallbackComm(rank, world, local_rank, torch_dist_transport(),
+                                name=f"{backend} through host memory (one-GPU rehearsal)")
         # threshold 0: every evaluation on non-negative data yields a candidate;
         # inter-robot matching only, as SURVEY §8e defines the step and as the node runs by default
-        # (frontend.enable_intra_robot_loop_closures = False, loop_closure_detection_node.py:36):
-        # per GPU the same 16 best-match evaluations per step as at N = 1.
+        # (frontend.enable_intra_robot_loop_closures = False, loop_closure_detection_node.py:36).
         # CSLAM_BENCH_INTRA=1 adds match_local_loop_closures (nb_best_matches = 10, lcsm.py:78-97).
-        intra = os.environ.get("CSLAM_BENCH_INTRA") == "1"
-        shard = DeviceShard(pool, rank, world, per_rank, 0.0, comm_d, comm_r,
+        shard = DeviceShard(pool, rank, nb_robots, per_rank, 0.0, comm, comm,
                             nb_best_matches=10 if intra else 0, intra_min_inbetween=10)
         blocks = torch.rand((8, per_rank, D), device=dev, generator=g)   # new keyframes, cycled
         next_kf = [N]
@@ -222,7 +232,7 @@ def main():
             state["published"] += 1
 
         def step(t):
-            # exchange of step t+1 first (own stream), then step t's append + scan + records;
+            # exchange of step t+1 first (own stream), then step t's scan + records;
             # the records of step t-1 are fetched while step t runs
             if state["published"] == state["matched"]:
                 publish()
@@ -257,9 +267,10 @@ def main():
     prof_every = 4 if args.steps >= 8 else 1
     _lib.check(L.cslam_pool_profile_begin_sampled(pool.handle, args.steps, prof_every))
     bytes0 = 0
-    if world > 1:
+    if nb_robots > 1:
         state["records"] = 0
-        bytes0 = comm_d.stats()["bytes_gathered"] + comm_r.stats()["bytes_gathered"]
+        bytes0 = comm.stats()["bytes_gathered"]
+        coll0 = comm.stats()["collectives"]
     fence()
     t0 = time.perf_counter()
     for t in range(args.steps):
@@ -273,48 +284,78 @@ def main():
     _lib.check(L.cslam_pool_profile_end(pool.handle, ctypes.byref(scan_ms), ctypes.byref(n_l)))
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # gloo, host tensor
         dt = float(tt.item())
-        sd, sr = comm_d.stats(), comm_r.stats()
-        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                     "transport": comm_d.transport, "rccl_version": sd["rccl_version"],
-                     "allgather_payload_bytes_per_step":
-                         (sd["bytes_gathered"] + sr["bytes_gathered"] - bytes0) / args.steps,
-                     "collectives_per_step": 3,
+    if nb_robots > 1:
+        sd = comm.stats()
+        dist_info = {"control_plane_backend": dist.get_backend() if world > 1 else None,
+                     "world_size": world, "robots": nb_robots,
+                     "transport": comm.transport if world > 1 else "loopback (one GPU: compute side of the step)",
+                     "rccl_ranks": comm.size() if world > 1 and backend == "nccl" else None,
+                     "rccl_version": sd["rccl_version"], "communicators": 1,
+                     "allgather_payload_bytes_per_step": (sd["bytes_gathered"] - bytes0) / args.steps,
+                     "collectives_per_step": (sd["collectives"] - coll0) / args.steps,
                      "match_records_per_step": state["records"] / args.steps,
-                     "new_descriptors_per_rank_per_step": per_rank}
+                     "new_descriptors_per_rank_per_step": per_rank,
+                     "gathered_descriptors_per_step": gathered_rows}
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * gathered_rows / (dt / args.steps)
+    # candidates evaluated per step: N = 1 (cfg2) all 16 best-match evaluations; sharded step: the
+    # FOREIGN descriptors of every rank (its own are skipped by the record kernel unless the
+    # intra-robot match is on)
+    evals_per_rank = gathered_rows if (nb_robots == 1 or intra) else gathered_rows - per_rank
+    value = world * evals_per_rank / (dt / args.steps)
 
-    # scan kernel roofline: algorithmic bytes of one launch:
-    #   pool rows N*D*4 + queries M*D*4 + results M*k*8
+    # scan kernel roofline: algorithmic bytes / flops of one launch:
+    #   pool rows N*D*4 + queries M*D*4 + results M*k*8;  2*N*D*M flop
     scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()
-    n_rows_scanned = N if world == 1 else N + (settle + args.warmup + args.steps // 2) * per_rank
-    k_sel = 1 if world == 1 else (per_rank + 10 if os.environ.get("CSLAM_BENCH_INTRA") == "1" else 2)
+    n_rows_scanned = N if nb_robots == 1 else N + (settle + args.warmup + args.steps // 2) * per_rank
+    k_sel = 1 if nb_robots == 1 else (per_rank + 10 if intra else 2)
     alg_bytes = n_rows_scanned * D * 4 + gathered_rows * D * 4 + gathered_rows * k_sel * 8
+    alg_flops = 2.0 * n_rows_scanned * D * gathered_rows
     achieved = alg_bytes / (scan_ms.value * 1e-3) / 1e9 if scan_ms.value > 0 else 0.0
     # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes and
-    # summarised in profiles/r02_scan_pmc.json; it is only quoted when that summary is about
-    # the kernel variant and the shape that ran here
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_scan_pmc.json")
-    if os.path.exists(pmc):
+    # summarised in profiles/r0X_scan_pmc.json; it is only quoted when that summary is about
+    # the kernel variant and the shape that ran here - `traffic_source` says where it came from
+    traffic, traffic_source = None, None
+    for name in ("r03_scan_pmc.json", "r02_scan_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc):
+            continue
         try:
             rec = json.load(open(pmc))
             if rec.get("kernel") == scan_kernel and rec.get("keyframes") == N and rec.get("dim") == D:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/" + name + " (separate rocprofv3 --pmc passes of this command, "
+                                  "not measured in this run)")
+                break
         except Exception:
-            traffic = None
+            pass
 
     workload = ("cfg2: 100k keyframes x 4096-d fp32 pool per GPU, 16 new descriptors per step, "
                 "best match (k=1) in the pool")
-    if world > 1:
-        workload = (f"cfg2 pool per GPU under the cfg4 protocol: every rank publishes {per_rank} new "
-                    "descriptors per step, RCCL all-gather, append, one scan of the pool for all "
-                    f"{gathered_rows} gathered descriptors (inter-robot match: best old row + best new row), match "
-                    "records built on the device, RCCL all-gather of the records, fetched by the host")
+    if nb_robots > 1:
+        where = ("RCCL all-gather" if world > 1 else "loopback all-gather (one GPU, robot 0 of %d)" % nb_robots)
+        workload = (("cfg4: %d keyframes x %d-d per robot, " % (N, D) if cfg4 else "cfg2 pool per GPU under the cfg4 protocol: ") +
+                    f"every robot publishes {per_rank} new descriptors per step, ONE {where} of blocks + ids, append, "
+                    f"one scan of the pool for all {gathered_rows} gathered descriptors (inter-robot match: best old "
+                    "row + best new row), match records built on the device, one all-gather of the records, "
+                    "fetched by the host")
+    # more than two query tiles: the scan is bound by the fp32 matrix pipe, not by HBM
+    mfma_bound = gathered_rows > 32
+    roofline = {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_peak": achieved / 6290.0,
+                "traffic": traffic, "traffic_source": traffic_source, "avg_kernel_ms": scan_ms.value,
+                "launches_timed": n_l.value, "launches_sampled_every": prof_every,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    if mfma_bound:
+        tf = alg_flops / (scan_ms.value * 1e-3) / 1e12 if scan_ms.value > 0 else 0.0
+        roofline.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
+                         "hbm_gbs": achieved})
+        roofline.pop("frac_of_measured_copy_peak", None)
     result = {
         "metric": METRIC,
         "value": value,
@@ -330,19 +371,15 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "keyframes_per_gpu": N, "dim": D,
-                   "queries_per_step_per_gpu": gathered_rows, "k": 1,
+                   "queries_per_step_per_gpu": gathered_rows,
+                   "evaluations_per_step_per_gpu": evals_per_rank, "k": 1,
                    "parallelism": f"robot-per-gpu x{world}"},
-        "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "frac_of_measured_copy_peak": achieved / 6290.0,
-                     "traffic": traffic, "avg_kernel_ms": scan_ms.value,
-                     "launches_timed": n_l.value, "launches_sampled_every": prof_every,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+        "roofline": roofline,
     }
     if dist_info:
         result["dist"] = dist_info
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not cfg4 and not args.no_extras:
         result["extras"] = extras(torch, L, _lib, pool, dev, g, stream, N, D, X)
         # the second half of the headline metric ("Fiedler-solve ms"), BASELINE.json configs[2]
         if "fiedler_cold_device_ms" in result["extras"]:
@@ -350,19 +387,45 @@ def main():
             result["select_candidates_20fw_ms"] = result["extras"]["fw_subset_20iters_ms"]
             if "acm_select_candidates_ms" in result["extras"]:   # graph assembly + MAC, end to end
                 result["acm_select_candidates_ms"] = result["extras"]["acm_select_candidates_ms"]
+            result["roofline_fiedler"] = fiedler_roofline(result["extras"])
         for key in ("value_incl_h2d", "value_append_then_search"):
             if key in result["extras"]:
                 result[key] = result["extras"][key]
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not cfg4 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(torch, X, new_local, out_idx, out_sim)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if nb_robots > 1:
         shard.close()
-        comm_d.close()
-        comm_r.close()
+        comm.close()
+    if world > 1:
         dist.destroy_process_group()
+
+
+def fiedler_roofline(ex):
+    """Second half of the headline metric against ITS bound.  The cfg3 Laplacian
+    with 500 active candidates is n = 50 000, nnz = n + 2 #E = 150 998: one SpMV reads
+    nnz*12 + (n+1)*4 + 2n*8 B = 2.81 MB - L2-resident (32 MiB of L2, 4 MiB per XCD), so the solve is
+    not HBM-bound but bound by the latency of the exchanges between the <= 64 co-resident
+    workgroups of the persistent kernel: per iteration `poll_points` rounds in which every workgroup
+    reads what the others published, each at the floor of one memory-side round trip
+    (tools/exchange_probe.hip: 1.6-1.8 us per all-to-all round at 25-49 workgroups)."""
+    n, nnz = 50_000, 50_000 + 2 * (49_998 + 1 + 500)
+    spmv_bytes = nnz * 12 + (n + 1) * 4 + 2 * n * 8
+    iters = ex.get("fiedler_cold_iters", 0)
+    ms = ex.get("fiedler_cold_device_ms", 0.0)
+    poll_points, round_trip_us = ex.get("fiedler_poll_points_per_iter", 2), 1.7
+    achieved = spmv_bytes * iters / (ms * 1e-3) / 1e9 if ms else 0.0
+    return {"bound": "latency (L2-resident working set; exchange rounds of the persistent kernel)",
+            "algorithmic_bytes_per_iteration": spmv_bytes, "iterations": iters, "device_ms": ms,
+            "achieved": achieved, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+            "residency": "2.8 MB per SpMV + ~2 MB of solver vectors: resident in L2/registers for the whole solve, "
+                         "HBM sees the operands once",
+            "us_per_iteration": ms * 1e3 / iters if iters else None,
+            "poll_floor_model": {"poll_points_per_iteration": poll_points, "round_trip_us": round_trip_us,
+                                 "floor_ms": iters * poll_points * round_trip_us * 1e-3,
+                                 "frac_of_floor": (iters * poll_points * round_trip_us * 1e-3) / ms if ms else None}}
 
 
 def extras(torch, L, _lib, pool, dev, g, stream, N, D, X):

@@ -423,6 +423,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
     static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
+#if defined(CSLAM_DMA_PROBE_CLOCK)   // timing probe (tools/build_mq_probes.sh): where a wave's time goes
+    const uint64_t pc_r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t pc_r1 = 0, pc_r2 = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     // the query norms are computed here when the epilogue needs them (BEST) or when the caller
     // skipped the staging kernel and wants them for the select (rnq_out)
@@ -518,6 +522,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     load_b<NB>(bn, qrow);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tie_b<NB>(bn);
+#if defined(CSLAM_DMA_PROBE_CLOCK)
+    pc_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // (Round 3 tried once more to request the first stages IN FRONT of this wait, for pools of a few
+    // strips per wave - the time line of a 25 000 x 4096-d scan is 2.6-3.2 us until the queries have
+    // landed, 2.5-3.5 more until the first stage has, then 66 us of streaming,
+    // profiles/r03_dma_probe_clock.txt.  It bought 1 us of 78 (profiles/r03_size_sweep_early.txt) and
+    // the variant aborted the process on 128-d pools of a few rows: not kept.)
 #pragma unroll
     for (int i = 0; i < NST; ++i)
         if (ic.p < p_end) {
@@ -582,6 +594,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 #pragma unroll
                     for (int i = 1; i < NST; ++i) yc = slot == i ? y[i] : yc;
                     wait_vm_dyn(yc);  // this stage's pieces have landed
+#if defined(CSLAM_DMA_PROBE_CLOCK)
+                    if (pc_r2 == 0) pc_r2 = __builtin_amdgcn_s_memrealtime();
+#endif
                     f32x4 a[16];
                     const char* ap = sp + rd_off;
 #pragma unroll
@@ -716,6 +731,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         cand[(int64_t)r * cand_stride + w] = wbest_a;
         if (cand_c != nullptr) cand_c[(int64_t)r * cand_stride + w] = wbest_c;
     }
+#if defined(CSLAM_DMA_PROBE_CLOCK)
+    if (lane == 0 && (w % 97) == 0) {
+        const uint64_t r3 = __builtin_amdgcn_s_memrealtime();
+        printf("dma probe: wave %4d rows %lld: entry %llu (x10 ns, absolute), queries landed +%llu, first stage landed +%llu, done +%llu\n",
+               w, (long long)(whi - wlo), (unsigned long long)(pc_r0 % 100000000ull), (unsigned long long)(pc_r1 - pc_r0),
+               (unsigned long long)(pc_r2 - pc_r0), (unsigned long long)(r3 - pc_r0));
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1498,17 +1521,6 @@ bool dma_scan_applies(const cslam_pool* p) {
     return p->vn >= kDmaMinRows;
 }
 
-// small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
-// of a block) instead of one wave walking every slice of its strip.  CSLAM_SCAN_KSPLIT=0 keeps
-// k_scan_dma.
-bool ks_scan_applies(const cslam_pool* p, int m) {
-    static const bool ks_env = !(getenv("CSLAM_SCAN_KSPLIT") && atoi(getenv("CSLAM_SCAN_KSPLIT")) == 0);
-    if (!ks_env || m > 16 || !dma_scan_applies(p) || p->dp % 256 != 0) return false;
-    const int64_t strips = (p->vn + 15) / 16;
-    const int nchunks = (p->dp / 256 + 1) / 2;
-    return strips <= p->cus && nchunks >= 4 && nchunks <= kKsMaxChunks;
-}
-
 // measurement knobs: read once — or at every launch when CSLAM_KNOBS_LIVE is set, so that a tool can
 // alternate settings inside one process (tools/reserve_ab.py; boxes and processes differ by
 // more than the effects in question)
@@ -1526,6 +1538,18 @@ int knob(Knob& k) {
         k.init = true;
     }
     return k.value;
+}
+
+// small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
+// of a block) instead of one wave walking every slice of its strip.  CSLAM_SCAN_KSPLIT=0 keeps
+// k_scan_dma.
+bool ks_scan_applies(const cslam_pool* p, int m) {
+    static const bool ks_env = !(getenv("CSLAM_SCAN_KSPLIT") && atoi(getenv("CSLAM_SCAN_KSPLIT")) == 0);
+    if (!ks_env || m > 16 || !dma_scan_applies(p) || p->dp % 256 != 0) return false;
+    const int64_t strips = (p->vn + 15) / 16;
+    const int nchunks = (p->dp / 256 + 1) / 2;
+    static Knob k_max{"CSLAM_SCAN_KSPLIT_ROUNDS", 1};   // strips up to this many per CU take the K-split kernel
+    return strips <= (int64_t)p->cus * knob(k_max) && nchunks >= 4 && nchunks <= kKsMaxChunks;
 }
 
 // k_scan_dma over the row window [v0, v0+vn): either raw dots (best = false) or one (similarity,

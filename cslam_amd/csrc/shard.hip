@@ -200,13 +200,41 @@ __global__ __launch_bounds__(256) void k_records_from_candidates(
     recs[3 * (int64_t)i + 2] = none;
 }
 
+// The gathered exchange buffer holds, per rank, [b_max][dim] fp32 rows followed by the (count,
+// keyframe ids) header: ONE all-gather per step instead of two.  This kernel copies the rows to the
+// dense [R * b_max][dim] block the scan reads its queries from and the headers to all_meta.
+__global__ __launch_bounds__(256) void k_unpack_exchange(const char* __restrict__ pack, int64_t per_rank_bytes,
+                                                         int64_t hdr_off, int R, int b_max, int dim,
+                                                         float* __restrict__ all_rows,
+                                                         int64_t* __restrict__ all_meta) {
+    const int s = blockIdx.y;
+    const char* src = pack + (int64_t)s * per_rank_bytes;
+    const int64_t n4 = (int64_t)b_max * dim / 4;   // dim is a multiple of 4 here (16-byte copies), else scalar
+    const float* rows = reinterpret_cast<const float*>(src);
+    float* dst = all_rows + (int64_t)s * b_max * dim;
+    if (((int64_t)b_max * dim) % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(rows)[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)b_max * dim; i += (int64_t)gridDim.x * 256)
+            dst[i] = rows[i];
+    }
+    if (blockIdx.x == 0) {
+        const int64_t* meta = reinterpret_cast<const int64_t*>(src + hdr_off);
+        for (int i = threadIdx.x; i < 1 + b_max; i += 256) all_meta[(int64_t)s * (1 + b_max) + i] = meta[i];
+    }
+}
+
 __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
 struct Slot {
-    float* all_rows = nullptr;        // [R][b_max][dim]   (own block at index me: in-place gather)
+    char* pack = nullptr;             // [R][per_rank_bytes]: rows [b_max][dim] + header, own part at index me
+                                      // (in-place all-gather: ONE collective for descriptors and ids)
+    float* all_rows = nullptr;        // [R][b_max][dim]   unpacked: the scan's query block
     int64_t* all_meta = nullptr;      // [R][1 + b_max]    count, keyframe ids
     int64_t* meta_host = nullptr;     // pinned [1 + b_max]
     int32_t* topk_idx = nullptr;      // [R*b_max][K]
@@ -239,6 +267,8 @@ struct cslam_shard {
     Slot slot[kSlots];
     int64_t pub_step = 0, match_step = 0, fetch_step = 0;
     int64_t rec_slots = 0;        // 3 * R * b_max
+    int64_t per_rank_bytes = 0;   // exchange payload of one rank: rows + header, 16-byte multiple
+    int64_t hdr_off = 0;          // byte offset of the header inside a rank's part (8-byte aligned)
 };
 
 namespace {
@@ -288,8 +318,15 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
         return fail(CSLAM_E_INVALID, "shard_create: communicator rank/size != robot id/count");
     if (comm_rec && (cslam_comm_size(comm_rec) != nb_robots || cslam_comm_rank(comm_rec) != robot_id))
         return fail(CSLAM_E_INVALID, "shard_create: record communicator rank/size mismatch");
-    if (comm_desc && comm_desc == comm_rec)
-        return fail(CSLAM_E_INVALID, "shard_create: the two exchanges overlap and need two communicators");
+    // comm_desc == comm_rec is allowed: both exchanges then run on ONE communicator and ONE stream, in
+    // the program order publish(t+1), match(t) of every rank - the simplest thing RCCL can be asked
+    // to do (the record exchange of step t waits for scan t, the descriptor exchange of step t+2
+    // queues behind it and still has the whole scan t+1 to complete in).
+    if (max_block + (nb_best_matches > 1 ? nb_best_matches : 1) > kFusedMaxK && nb_best_matches > 0)
+        return fail(CSLAM_E_INVALID,
+                    "shard_create: intra-robot matching (nb_best_matches = %d) needs max_block + nb_best_matches <= %d; "
+                    "a bulk block of %d is matched inter-robot only - pass nb_best_matches = 0",
+                    nb_best_matches, kFusedMaxK, max_block);
     cslam_shard* sh = new cslam_shard();
     sh->pool = pool;
     sh->comm_desc = comm_desc;
@@ -309,6 +346,8 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
     // old row, best row of the new block: one split best-match scan, no top-K lists
     sh->best2 = nb_best_matches == 0 && (int64_t)nb_robots * max_block <= 80;   // one scan pass (scan_mq.hip)
     sh->rec_slots = 3 * (int64_t)nb_robots * max_block;
+    sh->hdr_off = ((int64_t)max_block * sh->dim * (int64_t)sizeof(float) + 7) / 8 * 8;
+    sh->per_rank_bytes = (sh->hdr_off + (int64_t)(1 + max_block) * (int64_t)sizeof(int64_t) + 15) / 16 * 16;
     int rc = CSLAM_OK;
     hipError_t e = hipSetDevice(sh->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh->s_own, hipStreamNonBlocking);
@@ -317,6 +356,7 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
     for (int i = 0; i < kSlots && rc == CSLAM_OK; ++i) {
         Slot& s = sh->slot[i];
         auto A = [&](int r) { if (rc == CSLAM_OK) rc = r; };
+        A(dalloc(&s.pack, (size_t)nb_robots * sh->per_rank_bytes));
         A(dalloc(&s.all_rows, M * sh->dim));
         A(dalloc(&s.all_meta, (size_t)nb_robots * (1 + max_block)));
         A(dalloc(&s.recs_all, (size_t)nb_robots * sh->rec_slots));
@@ -355,7 +395,7 @@ int cslam_shard_destroy(cslam_shard_t* sh) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = sh->slot[i];
-        for (void* p : {(void*)s.all_rows, (void*)s.all_meta, (void*)s.topk_idx, (void*)s.topk_sim,
+        for (void* p : {(void*)s.pack, (void*)s.all_rows, (void*)s.all_meta, (void*)s.topk_idx, (void*)s.topk_sim,
                         (void*)s.idx_a, (void*)s.idx_c, (void*)s.sim_a, (void*)s.sim_c,
                         (void*)s.recs_all})
             if (p) (void)hipFree(p);
@@ -397,9 +437,11 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
     const int R = sh->R, me = sh->me, bm = sh->b_max, dim = sh->dim;
     s.meta_host[0] = b;
     for (int i = 0; i < bm; ++i) s.meta_host[1 + i] = i < b ? keyframe_ids[i] : -1;
-    int64_t* my_meta = s.all_meta + (int64_t)me * (1 + bm);
-    float* my_rows = s.all_rows + (int64_t)me * bm * dim;
-    // With peers, packing and both gathers run on the descriptor communicator's own stream, behind
+    // this rank's part of the exchange buffer: rows, then the header (in-place all-gather)
+    char* my_pack = s.pack + (int64_t)me * sh->per_rank_bytes;
+    float* my_rows = reinterpret_cast<float*>(my_pack);
+    int64_t* my_meta = reinterpret_cast<int64_t*>(my_pack + sh->hdr_off);
+    // With peers, packing and the gather run on the descriptor communicator's own stream, behind
     // an event on the producer's stream: the compute stream (the previous step's scan) is not
     // touched by a publish at all.
     hipStream_t ps = st;
@@ -421,11 +463,16 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
         CSLAM_TRY(pool_append_on(sh->pool, my_rows, b, dim, ps));
         CSLAM_TRY(ensure_kf_capacity(sh, s.n0 + b, ps));
     }
-    if (R > 1) {
-        CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_rows, s.all_rows,
-                                       (int64_t)bm * dim * sizeof(float), CSLAM_COMM_OWN_STREAM));
-        CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_meta, s.all_meta,
-                                       (int64_t)(1 + bm) * sizeof(int64_t), CSLAM_COMM_OWN_STREAM));
+    // ONE collective: rows and (count, keyframe ids) of every rank
+    if (R > 1)
+        CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_pack, s.pack, sh->per_rank_bytes, CSLAM_COMM_OWN_STREAM));
+    {
+        const int64_t n4 = (int64_t)bm * dim / 4;
+        unsigned gx = (unsigned)((n4 + 255) / 256);
+        gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+        hipLaunchKernelGGL(k_unpack_exchange, dim3(gx, R), dim3(256), 0, ps, s.pack, sh->per_rank_bytes, sh->hdr_off, R, bm,
+                           dim, s.all_rows, s.all_meta);
+        CSLAM_HIP_TRY(hipGetLastError());
     }
     CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, ps));
     s.b = b;

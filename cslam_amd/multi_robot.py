@@ -252,6 +252,10 @@ class RcclComm(object):
         _lib.check(_lib.load().cslam_comm_unique_id(buf))
         return bytes(buf)
 
+    def size(self):
+        """Ranks the communicator itself counts (cslam_comm_size: what RCCL was initialised with)."""
+        return int(self._L.cslam_comm_size(self.handle))
+
     def stats(self):
         b, n, v = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         self._lib.check(self._L.cslam_comm_stats(self.handle, ctypes.byref(b), ctypes.byref(n),
@@ -371,7 +375,8 @@ class DeviceShard(object):
         Args:
             pool: NearestNeighborsMatching (device pool of THIS robot; dim fixed)
             comm_desc, comm_rec: RcclComm/CallbackComm for the descriptor and the record exchange
-                                 (None for a single robot)
+                                 (None for a single robot); the SAME communicator may serve both
+                                 (one stream, one sequence of collectives per rank)
             nb_best_matches, intra_min_inbetween: frontend.nb_best_matches /
                 frontend.intra_loop_min_inbetween_keyframes; 0 disables the intra-robot match
         """
@@ -433,8 +438,9 @@ class DeviceShard(object):
         return self._buf[:n.value].copy()
 
     def apply(self, records):
-        """Feed fetched records to the selector replica; returns (inter-robot edges produced by
-        THIS rank, intra-robot matches [(keyframe, matched keyframe, similarity)])."""
+        """Feed fetched records to the selector replica; returns (the inter-robot edges of the step
+        - EVERY rank's, in rank order then descriptor order: all replicas apply the same list -,
+        this robot's intra-robot matches [(keyframe, matched keyframe, similarity)])."""
         mine, local = [], []
         for r in records:
             r0, k0, r1, k1, w = int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(np.float32(r[4]))

@@ -189,10 +189,16 @@ typedef struct {
 
 /* Rank-local half of the sharded matching step (csrc/shard.hip): robot `robot_id` owns `pool`
  * and nothing of the other robots' (the reference mirrors every peer pool,
- * loop_closure_sparse_matching.py:26-32).  comm_desc / comm_rec: two communicators over the same
- * ranks (descriptor and record exchange overlap each other); both NULL for a single robot.
- * nb_best_matches > 0 enables the intra-robot match of own keyframes
- * (match_local_loop_closures, lcsm.py:78-97) when max_block + nb_best_matches <= 64. */
+ * loop_closure_sparse_matching.py:26-32).  comm_desc / comm_rec: the communicators of the descriptor
+ * and of the record exchange over the same ranks - two (each exchange on a stream of its own), or
+ * the SAME one passed twice (both on one stream: every rank then issues exactly one sequence of
+ * collectives, publish(t+1), match(t), publish(t+2), ... - the form bench.py uses); both NULL for a
+ * single robot.  Collectives per step: ONE all-gather of [max_block][dim] rows + (count, keyframe
+ * ids) per rank at publish time, ONE all-gather of the match records at match time; every rank must
+ * call publish / match in the same order.
+ * nb_best_matches > 0 enables the intra-robot match of own keyframes (match_local_loop_closures,
+ * lcsm.py:78-97) and needs max_block + nb_best_matches <= 64 (CSLAM_E_INVALID otherwise: bulk
+ * blocks are matched inter-robot only, pass 0). */
 typedef struct cslam_shard cslam_shard_t;
 int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t* comm_rec,
                        int robot_id, int nb_robots, int max_block, double similarity_threshold,
@@ -202,12 +208,16 @@ int cslam_shard_destroy(cslam_shard_t* shard);
 int cslam_shard_set_keyframes(cslam_shard_t* shard, int64_t first, const int32_t* keyframe_ids,
                               int64_t n);
 /* Step part 1 — publish this robot's new block (b <= max_block rows in HBM, keyframe ids on
- * the host) and start the all-gather of everybody's blocks.  Asynchronous. */
+ * the host): the block is APPENDED TO THE POOL here (on the exchange stream, behind an event on
+ * `stream`, the stream that produced the rows) and the all-gather of everybody's blocks is started.
+ * Asynchronous.  Ordering contract: scans already in flight read rows below their own window only;
+ * every later call on the pool (any stream) is ordered behind the append; a growth of the pool or
+ * of the keyframe table drains the device first. */
 int cslam_shard_publish(cslam_shard_t* shard, const float* new_rows_dev, int64_t row_stride,
                         const int64_t* keyframe_ids, int b, void* stream);
-/* Step part 2 — for the oldest published step: append the own block, scan the pool for all
- * gathered descriptors, build the match records on the device, start their all-gather and the
- * copy to pinned host memory.  Asynchronous on `stream`. */
+/* Step part 2 — for the oldest published step: scan the pool (rows before / of the block that
+ * publish() appended) for all gathered descriptors, build the match records on the device, start
+ * their all-gather and the copy to pinned host memory.  Asynchronous on `stream`. */
 int cslam_shard_match(cslam_shard_t* shard, void* stream);
 /* Step part 3 — records of ALL ranks for the oldest matched step, rank order then descriptor
  * order (identical on every rank).  Blocks until that step has finished on the device. */

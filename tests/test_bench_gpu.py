@@ -34,7 +34,7 @@ def test_bench_single_gpu_line(gpu):
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["kernel"].startswith("k_scan_dma") and r["launches_timed"] >= 1
-    assert r["traffic"] is None                          # the PMC summary is about another shape
+    assert r["traffic"] is None and r["traffic_source"] is None   # the PMC summary is about another shape
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["algorithmic_bytes_per_launch"] == 20000 * 512 * 4 + 16 * 512 * 4 + 16 * 8
 
@@ -44,10 +44,28 @@ def test_bench_self_launches_two_ranks(gpu):
              {"CSLAM_BENCH_SAME_DEVICE": "1", "CSLAM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "robot-per-gpu x2"
     dist = d["dist"]
-    assert dist["world_size"] == 2 and dist["backend"] == "gloo"
-    assert dist["new_descriptors_per_rank_per_step"] == 8 and dist["collectives_per_step"] == 3
+    assert dist["world_size"] == 2 and dist["control_plane_backend"] == "gloo" and dist["communicators"] == 1
+    # ONE all-gather of blocks + ids at publish time, ONE of the records at match time
+    assert dist["new_descriptors_per_rank_per_step"] == 8 and abs(dist["collectives_per_step"] - 2) < 0.5
     # threshold 0 on non-negative data: every foreign descriptor matches its best old row
     assert dist["match_records_per_step"] >= 16
     assert dist["allgather_payload_bytes_per_step"] > 2 * 8 * 256 * 4
-    assert abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # only the FOREIGN descriptors are inter-robot evaluations: 8 of the 16 gathered ones per rank
+    assert d["config"]["evaluations_per_step_per_gpu"] == 8
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["roofline"]["kernel"].endswith("best>")     # the split best-match scan ran
+
+
+def test_bench_cfg4_workload_on_one_gpu(gpu):
+    """--workload cfg4 at N = 1: robot 0 of 8 over the loopback communicator, 10 descriptors per robot
+    and step, all 80 gathered ones matched in ONE k_scan_mq pass (toy pool size here)."""
+    d = _run(["--workload", "cfg4", "--keyframes", "6000", "--dim", "256", "--steps", "6", "--warmup", "2"])
+    assert d["n_gpus"] == 1 and d["config"]["queries_per_step_per_gpu"] == 80
+    assert d["config"]["evaluations_per_step_per_gpu"] == 70
+    assert abs(d["value"] - 70 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    dist = d["dist"]
+    assert dist["robots"] == 8 and dist["rccl_ranks"] is None and abs(dist["collectives_per_step"] - 2) < 0.5
+    assert dist["match_records_per_step"] >= 70
+    r = d["roofline"]
+    assert r["kernel"].startswith("k_scan_mq<T=5") and r["kernel"].endswith("best>")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9

@@ -194,8 +194,9 @@ def test_range_search_and_sharded_step_on_gpu(gpu):
 
 
 def test_gemm_tail_tiles_and_range_search_on_a_large_pool(gpu):
-    """(a) 200 queries against 70 000 rows: 1094 GEMM tiles = two whole waves of 128 x 128 tiles
-    plus a remainder that runs as 64 x 128 tiles (k_gemm_dma<1,2>) — bit-exact against the oracle.
+    """(a) 512 queries against 70 000 rows (the bulk regime: up to ~500 queries the k_scan_mq passes of
+    round 3 win): 2188 GEMM tiles = four whole waves of 128 x 128 tiles plus a remainder that runs
+    as 64 x 128 tiles (k_gemm_dma<1,2>) — bit-exact against the oracle.
     (b) the row-range search (what the sharded step uses) on a window large enough for the
     LDS-DMA scan, with a non-zero first row: indices are absolute, similarities identical."""
     torch = pytest.importorskip("torch")
@@ -204,7 +205,7 @@ def test_gemm_tail_tiles_and_range_search_on_a_large_pool(gpu):
     rs = np.random.RandomState(12)
     n, d = 70_000, 64
     X = (rs.rand(n, d).astype(np.float32) - 0.4)
-    Q = rs.rand(200, d).astype(np.float32)
+    Q = rs.rand(512, d).astype(np.float32)
     m = _pool(gpu, X, dim=d, capacity_hint=n)
     rows, sims = m.search_batch(Q, 3)
     assert gpu.cslam_pool_scan_kernel(m.handle).decode().startswith("k_gemm_dma")
@@ -630,9 +631,11 @@ def test_small_pool_k_split_scan_is_bit_identical(gpu, n, d, m, k):
 def test_narrow_gemm_tiles_for_129_to_192_queries(gpu):
     """k_gemm_dma<2,2,TJ=1> (128 x 64 tiles: three 64-query column blocks instead of two padded
     128-query ones) — same (k, k+4) operand pairing and chunk folds, bit-identical to the oracle;
-    a pool with a partial last row tile and more rows than one wave of tiles."""
+    a pool with a partial last row tile and more rows than one wave of tiles.  Since round 3 only
+    descriptors of <= 16 floats get here (everything longer takes k_scan_mq passes up to ~500
+    queries), hence the 16-d pool."""
     rs = np.random.RandomState(192)
-    n, d, m = 70_001, 512, 180
+    n, d, m = 70_001, 16, 180
     X = rs.rand(n, d).astype(np.float32) - 0.2
     Q = rs.rand(m, d).astype(np.float32) - 0.2
     pool = _pool(gpu, X, dim=d, capacity_hint=n)

@@ -133,7 +133,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_step_protocol_matches_sequential_reference(world):
     steps = 12
     oracle_knn.lib()  # build the oracle before forking workers

@@ -84,7 +84,7 @@ def _cfg4_fixture():
                                        "cfg4_ref.json")))
 
 
-def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM, thr=THR):
+def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM, thr=THR, one_comm=False):
     torch = pytest.importorskip("torch")
     from cslam_amd.multi_robot import CallbackComm, DeviceShard, LocalGroup
     from cslam_amd.nns_matching import NearestNeighborsMatching
@@ -97,7 +97,7 @@ def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM
             torch.cuda.set_device(0)
             pool = NearestNeighborsMatching(dim=dim)
             cd = CallbackComm(rank, world, 0, grp_d.transport(rank))
-            cr = CallbackComm(rank, world, 0, grp_r.transport(rank))
+            cr = cd if one_comm else CallbackComm(rank, world, 0, grp_r.transport(rank))
             sh = DeviceShard(pool, rank, world, max_block, thr, cd, cr, nb_best_matches=nb_best,
                              intra_min_inbetween=min_inbetween)
             mine, recs = [], []
@@ -114,7 +114,10 @@ def _run_shards(world, steps, blocks, max_block, nb_best, min_inbetween, dim=DIM
             local[rank] = mine
             records[rank] = np.concatenate(recs) if recs else None
             assert pool.n == sum(len(blocks[(t, rank)][1]) for t in range(steps))
-            sh.close(); cd.close(); cr.close(); pool.close()
+            sh.close(); cd.close()
+            if not one_comm:
+                cr.close()
+            pool.close()
         except Exception as e:  # surface worker failures in the main thread
             errors.append(e)
             grp_d.barrier.abort()
@@ -171,14 +174,14 @@ def test_device_shard_bulk_blocks(gpu):
             b = int(rs.randint(40, maxb + 1))
             blocks[(t, r)] = (rs.rand(b, DIM).astype(np.float32), list(range(nxt[r], nxt[r] + b)))
             nxt[r] += b
-    results, local, _ = _run_shards(world, steps, blocks, maxb, 10, 5)
+    results, local, _ = _run_shards(world, steps, blocks, maxb, 0, 0)
     union, _ = _sequential_reference_with(blocks, world, steps)
     assert len(union) > 20
     for r in range(world):
         assert set(results[r]) == set(union)
         for key in union:
             assert abs(results[r][key] - union[key]) <= 1e-7
-        assert local[r] == []                      # intra-robot matching is a fused-mode feature
+        assert local[r] == []                      # intra-robot matching is a fused-mode feature (refused below)
 
 
 def test_device_shard_bulk_thousands_of_descriptors_per_step(gpu):
@@ -192,13 +195,101 @@ def test_device_shard_bulk_thousands_of_descriptors_per_step(gpu):
             b = int(rs.randint(1500, maxb + 1))
             blocks[(t, r)] = (rs.rand(b, DIM).astype(np.float32), list(range(nxt[r], nxt[r] + b)))
             nxt[r] += b
-    results, _, _ = _run_shards(world, steps, blocks, maxb, 10, 5, thr=0.8)
+    results, _, _ = _run_shards(world, steps, blocks, maxb, 0, 0, thr=0.8)
     union, _ = _sequential_reference_with(blocks, world, steps, thr=0.8)
     assert len(union) > 200
     for r in range(world):
         assert set(results[r]) == set(union)
         for key in union:
             assert abs(results[r][key] - union[key]) <= 1e-7
+
+
+def test_intra_matching_with_bulk_blocks_is_refused(gpu):
+    """nb_best_matches > 0 needs max_block + nb_best_matches <= 64 (one fused top-K list per
+    descriptor); a bulk block with intra-robot matching requested is an error, not a silent
+    inter-robot-only shard."""
+    from cslam_amd import _lib
+    from cslam_amd.multi_robot import DeviceShard
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    pool = NearestNeighborsMatching(dim=64)
+    with pytest.raises(_lib.CslamHipError):
+        DeviceShard(pool, 0, 1, 70, 0.5, nb_best_matches=10, intra_min_inbetween=1)
+    sh = DeviceShard(pool, 0, 1, 70, 0.5, nb_best_matches=0)
+    sh.close(); pool.close()
+
+
+@pytest.mark.parametrize("world,maxb", [(8, 10), (5, 16)])
+def test_device_shard_split_best_mode_many_descriptors(gpu, world, maxb):
+    """cfg4's steady state: 8 robots x 10 descriptors per message (loop_closure_detection_node.py:34)
+    = 80 gathered descriptors, inter-robot matching only: ONE k_scan_mq pass with the split window
+    per step, records built from its candidates - against the sequential reference semantics; the
+    descriptor and the record exchange share ONE communicator (the form bench.py uses)."""
+    steps, dim = 6, 128
+    rs = np.random.RandomState(71 + world)
+    places = rs.rand(40, dim).astype(np.float32)
+    blocks, nxt = {}, [0] * world
+    for t in range(steps):
+        for r in range(world):
+            b = int(rs.randint(maxb - 3, maxb + 1))
+            x = places[rs.randint(0, len(places), size=b)] + 0.05 * rs.rand(b, dim).astype(np.float32)
+            blocks[(t, r)] = (x.astype(np.float32), list(range(nxt[r], nxt[r] + b)))
+            nxt[r] += b
+    results, local, records = _run_shards(world, steps, blocks, maxb, 0, 0, dim=dim, thr=0.9, one_comm=True)
+    union, _ = _sequential_reference_with(blocks, world, steps, thr=0.9)
+    assert len(union) > 50
+    for r in range(world):
+        assert set(results[r]) == set(union)
+        for key in union:
+            assert abs(results[r][key] - union[key]) <= 1e-7
+        assert results[r] == results[0]
+        assert records[r].tobytes() == records[0].tobytes()
+
+
+def test_pipelined_keyframe_table_growth(gpu):
+    """Round-2 advisor finding: the keyframe table grew (1024 -> 2048 rows) on the exchange stream
+    while the record kernel of an earlier step - queued on the MATCHING stream behind a scan - was
+    still to write its rows' ids into the old table; those ids were lost (records carried keyframe
+    -1).  Here: separate producer / matching streams, publish two steps ahead, the pool crosses
+    1000 (pool growth) and 1024 rows (table growth), and every step's first descriptor revisits a
+    row appended ONE step earlier - exactly the rows whose ids were at risk."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd.multi_robot import DeviceShard, LoopbackComm
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    R, me, b, dim, steps = 2, 0, 16, 4096, 12
+    rs = np.random.RandomState(12)
+    base = rs.rand(960, dim).astype(np.float32)
+    pool = NearestNeighborsMatching(dim=dim, capacity_hint=1000)
+    pool.add_items(base, [500000 + i for i in range(960)])
+    cd = LoopbackComm(me, R, 0)
+    sh = DeviceShard(pool, me, R, b, 0.5, cd, cd, nb_best_matches=0)
+    blocks = []
+    for t in range(steps):
+        x = rs.rand(b, dim).astype(np.float32)
+        if t > 0:
+            x[0] = blocks[t - 1][0][3]               # revisit row 3 of the previous block
+        blocks.append((x, [1000 * (t + 1) + i for i in range(b)]))
+    front, work = torch.cuda.Stream(), torch.cuda.Stream()
+    dev = [torch.from_numpy(x).cuda() for x, _ in blocks]
+    torch.cuda.synchronize()
+    got, pub = [], 0
+    for t in range(steps):
+        while pub < steps and pub <= t + 1:          # the exchange runs two steps ahead of the fetch
+            with torch.cuda.stream(front):
+                sh.publish(dev[pub], blocks[pub][1], front.cuda_stream)
+            pub += 1
+        sh.match(work.cuda_stream)
+        if t >= 1:
+            got.append(sh.fetch_records())
+    got.append(sh.fetch_records())
+    assert pool.n == 960 + steps * b
+    for t in range(1, steps):
+        recs = got[t]
+        # slot of the foreign copy (owner 1) of descriptor 0: best OLD row = row 3 of block t-1
+        mine = [r for r in recs if int(r[0]) == me and int(r[2]) == 1 and int(r[3]) == blocks[t][1][0]]
+        assert mine, f"step {t}: no record for the revisiting descriptor"
+        assert int(mine[0][1]) == blocks[t - 1][1][3], (t, mine[0])
+        assert all(int(r[1]) >= 0 and int(r[3]) >= 0 for r in recs)
+    sh.close(); cd.close(); pool.close()
 
 
 def test_device_shard_single_robot_and_pipelining(gpu):

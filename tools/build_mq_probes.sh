@@ -11,6 +11,11 @@ for v in ${PROBES:-NO_DMA NO_MFMA CLOCK}; do
   /opt/rocm/bin/hipcc $FLAGS -DCSLAM_MQ_PROBE_$v -c scan_mq.hip -o build/probe/scan_mq_$v.o &
 done
 wait
+if [ -n "$DMA_CLOCK" ]; then   # k_scan_dma with time stamps (knn.hip)
+  /opt/rocm/bin/hipcc $FLAGS -DCSLAM_DMA_PROBE_CLOCK -c knn.hip -o build/probe/knn_DMA_CLOCK.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe_libs/libcslam_hip_DMA_CLOCK.so \
+     build/common.o build/probe/knn_DMA_CLOCK.o build/scan_mq.o build/mac.o build/geom.o build/comm.o build/shard.o -ldl
+fi
 for v in ${PROBES:-NO_DMA NO_MFMA CLOCK}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probe_libs/libcslam_hip_$v.so \
      build/common.o build/knn.o build/probe/scan_mq_$v.o build/mac.o build/geom.o build/comm.o build/shard.o -ldl
