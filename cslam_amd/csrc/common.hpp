@@ -91,6 +91,15 @@ int device_cu_count(int device_id, int* cus);
 int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64_t row_stride,
                    hipStream_t st);
 int pool_order_on(cslam_pool_t* p, hipStream_t st);
+// While on, pool calls do not wait for an append queued on another stream (pool_append_on): the
+// shard's own searches work on the explicit row windows of THEIR step and are ordered behind that
+// step's publish event; the append they would wait for belongs to a later step of the pipeline.
+void pool_internal_scope(cslam_pool_t* p, bool on);
+struct PoolInternalScope {
+    cslam_pool_t* p;
+    explicit PoolInternalScope(cslam_pool_t* pool) : p(pool) { pool_internal_scope(p, true); }
+    ~PoolInternalScope() { pool_internal_scope(p, false); }
+};
 // candidates of a split best-match scan, see knn.hip
 struct BestCandidates {
     const uint64_t* a = nullptr;  // [m][stride] composites of rows < split, n valid per query

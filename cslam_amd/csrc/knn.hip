@@ -1419,6 +1419,10 @@ struct cslam_pool {
     hipEvent_t app_ev = nullptr;
     hipStream_t app_stream = nullptr;
     bool app_pending = false;
+    // set by the shard around ITS OWN searches (pool_internal_scope): they run on explicit row
+    // windows behind the publish event of their own step and must not wait for the append of a
+    // LATER step, which the pipelined exchange has already queued
+    bool internal_caller = false;
 };
 
 namespace {
@@ -1427,7 +1431,7 @@ namespace {
 int order_after_dev(cslam_pool* p, hipStream_t st) {
     if (p->dev_pending && p->dev_stream != st)
         CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->dev_ev, 0));
-    if (p->app_pending && p->app_stream != st) {
+    if (p->app_pending && p->app_stream != st && !p->internal_caller) {
         // the append was issued a whole step ahead of the scan that needs it: normally it is
         // complete, and then the stream is spared the cross-stream barrier packet (~10 us in
         // front of a scan, profiles/r02_shard_step_timeline.txt)
@@ -2629,6 +2633,9 @@ int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64
     p->app_stream = st;
     p->app_pending = true;
     return CSLAM_OK;
+}
+void pool_internal_scope(cslam_pool_t* p, bool on) {
+    if (p) p->internal_caller = on;
 }
 int pool_order_on(cslam_pool_t* p, hipStream_t st) {
     if (!p) return fail(CSLAM_E_INVALID, "pool_order_on: null");

@@ -495,6 +495,9 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     // scan cost ~10 us of the 17-us gap between two steps, profiles/r02_shard_step_timeline.txt)
     if (hipEventQuery(s.ev_pub) != hipSuccess) CSLAM_HIP_TRY(hipStreamWaitEvent(st, s.ev_pub, 0));
     const int64_t n0 = s.n0, hi = s.n0 + s.b;   // the own block was appended by publish()
+    // this step's searches read rows [0, hi) only, complete since ev_pub: they do not wait for the
+    // appends of later steps that the exchange stream has already queued
+    PoolInternalScope internal(sh->pool);
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
     const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);
     if (R == 1 && sh->k_local == 0) {

@@ -18,8 +18,8 @@ from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 nb_best = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-N, D = 100_000, 4096
-per_rank = 16 // R
+N, D = int(os.environ.get("SHARD_ROWS", 100_000)), 4096
+per_rank = int(os.environ.get("SHARD_PER_RANK", 16 // R))   # cfg4: SHARD_ROWS=25000 SHARD_PER_RANK=10, R = 8
 L = _lib.load()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -30,7 +30,7 @@ pool.add_items_device(X.data_ptr(), N, D, items=None, stream=st)
 
 
 cd = LoopbackComm(0, R, 0)
-cr = LoopbackComm(0, R, 0)
+cr = cd if os.environ.get("SHARD_ONE_COMM", "1") == "1" else LoopbackComm(0, R, 0)
 sh = DeviceShard(pool, 0, R, per_rank, 0.0, cd, cr, nb_best_matches=nb_best, intra_min_inbetween=10)
 blocks = torch.rand((8, per_rank, D), device=dev, generator=g)
 kf = [N]
