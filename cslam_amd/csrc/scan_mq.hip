@@ -525,21 +525,26 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 // ---------------------------------------------------------------------------------------------
 template <bool BEST>
 __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, int nchunks, int64_t cand_off) {
-    const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // one wave per (strip, tile): its <= 16 chunk partials are requested together, folded in order
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t strip = wv / tiles;
+    const int t = (int)(wv % tiles);
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const int64_t lo = strip << 4;
     if (lo >= A.n) return;
     const int64_t hi = lo + 16 < A.n ? lo + 16 : A.n;
     const int rows = (int)(hi - lo);
-    f32x4 tot[5];
+    const f32x4* src = A.part + ((strip * nchunks) * tiles + t) * 64 + lane;
+    f32x4 part[16];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* src = A.part + (strip * nchunks) * tiles * 64 + lane;
-    for (int c = 0; c < nchunks; ++c)
+    for (int c = 0; c < 16; ++c)
+        part[c] = c < nchunks ? src[(int64_t)c * tiles * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 tot{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
-            if (t < tiles) tot[t] = tot[t] + src[((int64_t)c * tiles + t) * 64];
+    for (int c = 0; c < 16; ++c)
+        if (c < nchunks) tot = tot + part[c];
+    for (int c = 16; c < nchunks; ++c) tot = tot + src[(int64_t)c * tiles * 64];   // dp > 8192
     if (BEST) {
         float rn[4];
 #pragma unroll
@@ -550,50 +555,40 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
         const bool two = A.split < hi;
         const uint32_t rbase = A.row0 + (uint32_t)lo;
         const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
+        const float rq = A.rnq[16 * t + r];
+        uint64_t best = 0, best_c = 0;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            if (t < tiles) {
-                const float rq = A.rnq[16 * t + r];
-                uint64_t best = 0, best_c = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int rel = 4 * g + e;
-                    const float sim = (tot[t][e] * rn[e]) * rq;
-                    uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
-                    c = rel < rows ? c : 0;
-                    if (two) {
-                        const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
-                        best = ca > best ? ca : best;
-                        best_c = cc > best_c ? cc : best_c;
-                    } else {
-                        best = c > best ? c : best;
-                    }
-                }
-                uint64_t o = __shfl_xor(best, 16, 64);
-                best = o > best ? o : best;
-                o = __shfl_xor(best, 32, 64);
-                best = o > best ? o : best;
-                o = __shfl_xor(best_c, 16, 64);
-                best_c = o > best_c ? o : best_c;
-                o = __shfl_xor(best_c, 32, 64);
-                best_c = o > best_c ? o : best_c;
-                if (g == 0 && 16 * t + r < A.m_valid) {
-                    A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best;
-                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best_c;
-                }
+        for (int e = 0; e < 4; ++e) {
+            const int rel = 4 * g + e;
+            const float sim = (tot[e] * rn[e]) * rq;
+            uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+            c = rel < rows ? c : 0;
+            if (two) {
+                const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
+                best = ca > best ? ca : best;
+                best_c = cc > best_c ? cc : best_c;
+            } else {
+                best = c > best ? c : best;
             }
         }
-    } else {
+        uint64_t o = __shfl_xor(best, 16, 64);
+        best = o > best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o > best ? o : best;
+        o = __shfl_xor(best_c, 16, 64);
+        best_c = o > best_c ? o : best_c;
+        o = __shfl_xor(best_c, 32, 64);
+        best_c = o > best_c ? o : best_c;
+        if (g == 0 && 16 * t + r < A.m_valid) {
+            A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best;
+            if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best_c;
+        }
+    } else if (16 * t + r < A.m_valid) {
         const int64_t r0 = lo + 4 * g;
+        float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            if (t < tiles && 16 * t + r < A.m_valid) {
-                float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (r0 + e < hi) out[e] = tot[t][e];
-            }
-        }
+        for (int e = 0; e < 4; ++e)
+            if (r0 + e < hi) out[e] = tot[e];
     }
 }
 
@@ -685,7 +680,7 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
 int launch_mq_combine(const MqArgs& a, int tiles, int nchunks, bool best, int64_t cand_off, hipStream_t st) {
     const int64_t strips = (a.n + 15) >> 4;
     if (strips <= 0) return CSLAM_OK;
-    const unsigned grid = (unsigned)((strips + 3) / 4);
+    const unsigned grid = (unsigned)((strips * tiles + 3) / 4);   // one wave per (strip, tile)
     if (best)
         hipLaunchKernelGGL((k_mq_combine<true>), dim3(grid), dim3(256), 0, st, a, tiles, nchunks, cand_off);
     else
