@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     int gstep = 0;
 #if defined(CSLAM_MQ_PROBE_CLOCK)   // timing probe: shader clock held inside the stage loop
     const uint64_t pc_t0 = __builtin_amdgcn_s_memtime(), pc_r0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t pc_wait_b = 0, pc_wait_bar = 0;
+    uint64_t pc_wait_b = 0, pc_wait_bar = 0, pc_body = 0;
 #endif
     for (int rd = 0; rd < P; ++rd) {
         const int rows = panel_rows(rd);
@@ -302,6 +302,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     // order, so every read of the slot has returned before anything overwrites it.
                     const int nslot = slot + 1 == NST ? 0 : slot + 1;
                     const char* nx = ring + nslot * kStage + rd_off;
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+                    const uint64_t pc_s0 = __builtin_amdgcn_s_memtime();
+#endif
                     if (PF && s == 0) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage);
@@ -384,6 +387,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                             for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
                         }
                     });
+#if defined(CSLAM_MQ_PROBE_CLOCK)
+                    pc_body += __builtin_amdgcn_s_memtime() - pc_s0;
+#endif
                     issued += NP;
                     if (s == 0) mark_b = issued;   // an upper bound of the last B piece's position: a longer wait at worst
                     i_advance();
@@ -499,9 +505,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
         const uint64_t dt = __builtin_amdgcn_s_memtime() - pc_t0, dr = __builtin_amdgcn_s_memrealtime() - pc_r0;
         if ((blockIdx.x == 3 || blockIdx.x == 100) && threadIdx.x == 0 && MODE != MODE_PART)
             printf("mq clock probe: block %d T=%d NW=%d: %llu shader cycles in %llu x 10 ns = %.3f GHz, %.1f cycles per MFMA; "
-                   "of them waiting for B %llu, at the barrier %llu (%d steps)\n",
+                   "of them waiting for B %llu, at the barrier %llu (%d steps), inside the k-block loops of the stages %llu\n",
                    (int)blockIdx.x, T, NW, (unsigned long long)dt, (unsigned long long)dr, (double)dt / (10.0 * dr),
-                   (double)dt / ((double)J * NB * 4 * T), (unsigned long long)pc_wait_b, (unsigned long long)pc_wait_bar, gstep);
+                   (double)dt / ((double)J * NB * 4 * T), (unsigned long long)pc_wait_b, (unsigned long long)pc_wait_bar, gstep,
+                   (unsigned long long)pc_body);
     }
 #endif
     if (MODE == MODE_BEST && g == 0) {   // rounds this block does not have (blocks differ by one row)
