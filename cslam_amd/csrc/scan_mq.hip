@@ -76,6 +76,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     constexpr int kBAfterX = (NBP / NB) * (NB - kLastX) + ((NBP % NB) > kLastX ? (NBP % NB) - kLastX : 0);
     constexpr bool PF = NW == 4;          // B fragments of the next k-block prefetched into a second register set
     static_assert(NP == NB && NB >= 4 && (NW == 4 || NW == 8), "geometry");
+    static_assert((T - PPK) * NB >= NBPX, "every B piece needs a slot behind a chain t >= PPK of the first stage");
     extern __shared__ __attribute__((aligned(16))) char mq_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -164,12 +165,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                                          16, 0, AUX);
     };
     auto i_advance = [&]() {
-        if (i_left <= 1) {   // nothing behind the last stage: the cursor stays (dummy refills)
+        // (the likely path first: every taken branch between two stages costs the wave an instruction
+        // buffer refill with nothing on the matrix pipe)
+        if (__builtin_expect(i_left <= 1, 0)) {   // nothing behind the last stage: the cursor stays (dummy refills)
             i_left = 0;
             return;
         }
         --i_left;
-        if (++i_s < i_ns) {            // next strip of the slice
+        if (__builtin_expect(++i_s < i_ns, 1)) {            // next strip of the slice
             i_base += strip_b;
             i_last -= 16;
             return;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
         i_base -= (int64_t)(i_s - 1) * strip_b;   // back to the panel's first strip
         i_last += 16 * (i_s - 1);
         i_s = 0;
-        if (++i_kc < nkc) {            // next slice
+        if (__builtin_expect(++i_kc < nkc, 1)) {            // next slice
             i_base += KW * 4;
             return;
         }
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             f32x4 bcur[T];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if (s < ns) {
+                if (__builtin_expect(s < ns, 1)) {
                     // `a` holds this stage (read while the previous one was multiplied).  Its slot is
                     // refilled piece by piece BEHIND the k-blocks: the first DMA follows MFMAs that
                     // waited for B fragments read after the last of those `a` reads - LDS returns in
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     i_advance();
 #pragma unroll
                     for (int t = 0; t < T; ++t) asm volatile("" : "+a"(acc[s][t]));
-                    if (fold) {
+                    if (__builtin_expect(fold, 0)) {
                         if (MODE == MODE_PART) {
                             // the partial of chunk c of this strip, in the layout k_mq_combine folds
                             const int64_t strip = (lo >> 4) + s;   // panels are strip-aligned
