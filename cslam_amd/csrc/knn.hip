@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                                                       int64_t cand_stride,
                                                       float* __restrict__ rnq_out,
                                                       int64_t split, uint64_t* __restrict__ cand_c,
-                                                      int even, int early) {
+                                                      int even) {
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
     static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
@@ -519,39 +519,28 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         for (int i = 0; i < NST; ++i) y[i] += k;
         yq += k;
     };
-    // Small pools (a few strips per wave): the first stages are requested IN FRONT of the query
-    // fragments, so that the two round trips of the prologue overlap - a wave's time line at
-    // 25 000 x 4096-d was 2.6-3.2 us until its queries had landed, another 2.5-3.5 until its first
-    // stage had, then 66 us of streaming (profiles/r03_dma_probe_clock.txt).  The asm loads stay
-    // IMMEDIATELY in front of their wait and tie in both orders: compiler-generated code between an
-    // asm load and its wait may recycle the registers the load still owes (item 10 of DESIGN.md
-    // section 5 - round 3's first attempt at this put the stage issue into that window and faulted).
-    if (early) {
-#pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (ic.p < p_end) {
-                const int c = issue(ic, ring + i * kStage);
-                bump(c);
-                y[i] = 0;
-                advance(ic);
-            }
-    }
     load_b<NB>(bn, qrow);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tie_b<NB>(bn);
 #if defined(CSLAM_DMA_PROBE_CLOCK)
     pc_r1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (!early) {
+    // (Round 3 tried once more to request the first stages IN FRONT of this wait, for pools of a few
+    // strips per wave - the time line of a 25 000 x 4096-d scan is 2.6-3.2 us until the queries have
+    // landed, 2.5-3.5 more until the first stage has, then 66 us of streaming,
+    // profiles/r03_dma_probe_clock.txt.  With the stage issue BETWEEN the asm loads and their wait it
+    // bought 1 us of 78 (profiles/r03_size_sweep_early.txt) and faulted on its first small pool: the
+    // window let the compiler recycle registers the loads still owed.
+    // With the stages issued in front of the asm loads - no window - it is safe (121 tests) and buys
+    // nothing (profiles/r03_size_sweep_early2.txt: 77.1-78.7 vs 75.8-79.2 us): not kept.)
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (ic.p < p_end) {
-                const int c = issue(ic, ring + i * kStage);
-                bump(c);
-                y[i] = 0;
-                advance(ic);
-            }
-    }
+    for (int i = 0; i < NST; ++i)
+        if (ic.p < p_end) {
+            const int c = issue(ic, ring + i * kStage);
+            bump(c);
+            y[i] = 0;
+            advance(ic);
+        }
 
     int slot = 0;  // ring slot of the stage the consumer is at
     uint64_t wbest_a = 0, wbest_c = 0;  // BEST: this wave's best composites (lanes g == 0)
@@ -1608,10 +1597,6 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     // + 8 + 1 instead of 4 x 7) but a remainder panel pays the whole per-panel cost — equal panels
     // win or tie from 256-d to 2048-d (1024-d 0.2597 vs 0.2633 ms), lose 2 % at 128-d
     const int even = knob(k_even) == 0 ? 0 : 1;
-    // stages requested in front of the query fragments (prologue round trips overlapped): pools of up
-    // to four strips per wave; CSLAM_SCAN_EARLY=0 / 1 forces
-    static Knob k_early{"CSLAM_SCAN_EARLY", -1};
-    const int early = knob(k_early) >= 0 ? (knob(k_early) ? 1 : 0) : (strips <= 4 * n_waves ? 1 : 0);
     // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
     const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
 
@@ -1636,7 +1621,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
                            lds, st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride,    \
                            q_rows, m, dots, dots_stride, (int)n_waves,                            \
                            p->inv_norm + p->v0, (uint32_t)p->v0, cand, cand_stride, rnq_out,      \
-                           split, cand_c, even, early);                                           \
+                           split, cand_c, even);                                                  \
     } while (0)
 #define CSLAM_DMA_LAUNCH_KW(AUX, BEST)                   \
     do {                                                 \

@@ -1,5 +1,5 @@
 """16 best-match queries (k_scan_dma) over pools of 5k..100k rows x 4096-d: kernel time by HIP events and
-TB/s of the rows read, alternating CSLAM_SCAN_EARLY=0 / 1 in one process (CSLAM_KNOBS_LIVE)."""
+TB/s of the rows read, (round 3: the CSLAM_SCAN_EARLY knob it alternated was an experiment that is no longer in the library)."""
 import ctypes, os, sys, time
 os.environ["CSLAM_KNOBS_LIVE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
