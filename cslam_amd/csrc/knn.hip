@@ -407,7 +407,7 @@ struct DmaCursor {   // position of a stage in a wave's work list
 //   holds global segment j ^ k) and the piece pitch is 1024 + 32 B (R <= 2) or 1024 + 64 B
 //   (R = 4), so that the 16 lanes of a ds_read_b128 pass — 16 rows at one k offset — hit 16
 //   different 16-B slots.  Same chain order, same folds: same bits.
-template <int NS, int NW, int NST, int AUX, bool BEST, int KW = 256>
+template <int NS, int NW, int NST, int AUX, bool BEST, int KW = 256, bool DOTS_TOO = false>
 __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ X, int64_t xs,
                                                       int64_t n, int dp,
                                                       const float* __restrict__ Q, int64_t q_stride,
@@ -717,7 +717,11 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                 best_c = o > best_c ? o : best_c;
                 wbest_c = best_c > wbest_c ? best_c : wbest_c;
             }
-        } else if (r < m_valid) {
+        }
+        // raw dots out: the plain dots mode, or (DOTS_TOO, search with 2 <= k <= 16) next to the
+        // per-wave best composites - the k best waves then bound where the k best rows can be and
+        // the select reads the dots of those waves' rows only (k_topk_from_waves)
+        if ((!BEST || DOTS_TOO) && r < m_valid) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (s < ns) {
@@ -1365,6 +1369,161 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
     out_sim[j] = -INFINITY;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_topk_from_waves: exact top-k (2 <= k <= 16) of ONE query per block from what the fused scan left:
+// the best (similarity, row) composite of every wave (cand) and the raw dots of every row.
+//   The k-th best row is at least as good as the k-th best WAVE maximum (k distinct waves hold k
+//   distinct rows that good), and a wave whose maximum is below it holds no row of the top k: the
+//   candidates are the rows of the k best waves - ~k x 112 rows of the 100 000.  Round 2 ran k
+//   block-wide arg-max rounds over every 4096 rows of the pool plus a merge level (14 + 9 us and a
+//   6.4-MB dots read); this is one launch over ~1100 rows, and no serial rounds: selections are
+//   by RANK (composites are unique: #{others greater} is the output position).
+//   A1  every thread takes <= 4 wave maxima; a hardware wave ranks its 64 thread maxima by their
+//       similarity word (64 readlanes) -> the k-th largest is a lower bound of the k-th best
+//       wave maximum; T1 = the best of the four bounds.
+//   A2  wave maxima >= T1 (a few times k of the ~1000) go to an LDS list with their wave number.
+//   A3  rank inside the list: ranks < k are the k best waves, rank k-1 is the bound Tk.
+//   B1  composites of those waves' rows (dot x 1/||x|| x 1/||q||, as every other path; the row
+//       ranges follow from the scan's even split of the window over n_waves); those >= Tk (k of
+//       them at least, rarely many more) go to the list.
+//   B2  rank inside the list = output position.  A list overflow (> 1024 rows at or above the
+//       bound: an all-zero query over waves of > 64 rows) takes k rounds of block arg-max instead.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTopkWavesMaxK = 16;
+constexpr int kTopkWavesMax = 1024;   // scan waves (= 4 x CUs at most) and list entries
+__global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restrict__ cand, int64_t cand_stride,
+                                                         int n_waves, const float* __restrict__ dots,
+                                                         int64_t dots_stride, const float* __restrict__ rnx,
+                                                         const float* __restrict__ rnq, uint32_t row0, int64_t n,
+                                                         int k, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_sim) {
+    __shared__ uint64_t lst[kTopkWavesMax];
+    __shared__ uint16_t lst_w[kTopkWavesMax];
+    __shared__ uint64_t wmax[2][4];
+    __shared__ uint64_t tk_s;
+    __shared__ uint32_t tw[4];
+    __shared__ int64_t w_lo[kTopkWavesMaxK];
+    __shared__ int w_cnt[kTopkWavesMaxK], w_pre[kTopkWavesMaxK + 1];
+    __shared__ int cnt1, cnt2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
+    const int64_t wq = n / n_waves, wrem = n - wq * n_waves;
+    if (tid == 0) {
+        cnt1 = 0;
+        cnt2 = 0;
+        tk_s = 0;
+    }
+    // ---- A1: a lower bound of the k-th best wave maximum ------------------------------------
+    uint64_t wm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wm[e] = e * 256 + tid < n_waves ? cand[q * cand_stride + e * 256 + tid] : 0;
+    uint64_t gm = wm[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) gm = wm[e] > gm ? wm[e] : gm;
+    const uint32_t ghi = (uint32_t)(gm >> 32);   // an empty thread has 0, below every real similarity word
+    int above = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) above += (uint32_t)__builtin_amdgcn_readlane((int)ghi, j) > ghi ? 1 : 0;
+    // the lanes with fewer than k similarity words above theirs hold the k largest: the least of those
+    uint32_t kth = above < k ? ghi : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t v = (uint32_t)__shfl_xor((int)kth, o, 64);
+        kth = v < kth ? v : kth;
+    }
+    if (lane == 0) tw[wave] = kth;
+    __syncthreads();
+    uint32_t t1 = tw[0];
+#pragma unroll
+    for (int x = 1; x < 4; ++x) t1 = tw[x] > t1 ? tw[x] : t1;
+    // ---- A2: the wave maxima at or above the bound --------------------------------------------
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (wm[e] != 0 && (uint32_t)(wm[e] >> 32) >= t1) {
+            const int pos = atomicAdd(&cnt1, 1);
+            lst[pos] = wm[e];
+            lst_w[pos] = (uint16_t)(e * 256 + tid);
+        }
+    __syncthreads();
+    const int s1 = cnt1;
+    const int nwin = s1 < k ? s1 : k;
+    // ---- A3: rank -> the k best waves and the bound Tk ----------------------------------------
+    for (int i = tid; i < s1; i += 256) {
+        const uint64_t c = lst[i];
+        int rank = 0;
+        for (int j = 0; j < s1; ++j) rank += lst[j] > c ? 1 : 0;
+        if (rank < k) {
+            const int64_t w = lst_w[i];
+            w_lo[rank] = w * wq + (w < wrem ? w : wrem);
+            w_cnt[rank] = (int)(wq + (w < wrem ? 1 : 0));
+            if (rank == k - 1) tk_s = c;
+        }
+    }
+    __syncthreads();
+    if (tid <= nwin) {
+        int pre = 0;
+        for (int j = 0; j < tid; ++j) pre += w_cnt[j];
+        w_pre[tid] = pre;
+    }
+    __syncthreads();
+    const int total = w_pre[nwin];
+    const uint64_t tk = tk_s;
+    const float rq = rnq[q];
+    auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
+        int j = 0;
+        while (j + 1 < nwin && idx >= w_pre[j + 1]) ++j;
+        const int64_t row = w_lo[j] + (idx - w_pre[j]);
+        return make_comp((dots[q * dots_stride + row] * rnx[row]) * rq, row0 + (uint32_t)row);
+    };
+    // ---- B1: the rows of those waves at or above Tk --------------------------------------------
+    for (int idx = tid; idx < total; idx += 256) {
+        const uint64_t c = comp_at(idx);
+        if (c >= tk) {
+            const int pos = atomicAdd(&cnt2, 1);
+            if (pos < kTopkWavesMax) lst[pos] = c;
+        }
+    }
+    __syncthreads();
+    const int s2 = cnt2;
+    if (s2 <= kTopkWavesMax) {
+        // ---- B2: rank = output position ---------------------------------------------------------
+        for (int i = tid; i < s2; i += 256) {
+            const uint64_t c = lst[i];
+            int rank = 0;
+            for (int j = 0; j < s2; ++j) rank += lst[j] > c ? 1 : 0;
+            if (rank < k) {
+                out_idx[q * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFu));
+                out_sim[q * k + rank] = ord2f((uint32_t)(c >> 32));
+            }
+        }
+        for (int j = s2 + tid; j < k; j += 256) {   // fewer rows than k
+            out_idx[q * k + j] = -1;
+            out_sim[q * k + j] = -INFINITY;
+        }
+        return;
+    }
+    // ---- overflow: k rounds of block arg-max over the candidates, each below the previous winner
+    uint64_t last = ~0ull;
+    for (int rd = 0; rd < k; ++rd) {
+        uint64_t mt = 0;
+        for (int idx = tid; idx < total; idx += 256) {
+            const uint64_t c = comp_at(idx);
+            mt = (c < last && c > mt) ? c : mt;
+        }
+        const uint64_t m = wave_max_u64(mt);
+        if (lane == 0) wmax[rd & 1][wave] = m;
+        __syncthreads();
+        uint64_t win = wmax[rd & 1][0];
+#pragma unroll
+        for (int x = 1; x < 4; ++x) win = wmax[rd & 1][x] > win ? wmax[rd & 1][x] : win;
+        if (tid == 0) {
+            out_idx[q * k + rd] = win ? (int32_t)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu)) : -1;
+            out_sim[q * k + rd] = win ? ord2f((uint32_t)(win >> 32)) : -INFINITY;
+        }
+        last = win;   // 0 when nothing is left: the remaining rounds write the empty result
+    }
+}
+
 // final level of search_best: one block per (query, window) reduces the waves' composites.
 // window 1 (blockIdx.y == 1) exists for the split search only.
 __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ cand_a,
@@ -1564,8 +1723,10 @@ bool ks_scan_applies(const cslam_pool* p, int m) {
 int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows, int m, float* dots,
                     int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride,
                     int64_t* n_panels_out, hipStream_t st, float* rnq_out = nullptr,
-                    int64_t split = -1, uint64_t* cand_c = nullptr) {
+                    int64_t split = -1, uint64_t* cand_c = nullptr, bool dots_too = false) {
     constexpr int NS = 8, NW = 4, NST = 2;
+    if (dots_too && (!best || dots == nullptr || rnq_out == nullptr || cand_c != nullptr))
+        return fail(CSLAM_E_INVALID, "scan_dma: dots_too needs best, dots, rnq_out and one window");
     // CSLAM_SCAN_RESERVE_CUS=n leaves n CUs to kernels of other streams (the scan's blocks fill a
     // CU each — LDS and registers — so a collective's workgroup that sits on one when the scan
     // starts pushes a scan block into a second round: tools/shard_step_time.py with
@@ -1607,27 +1768,27 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     // pool rows are read once per search: non-temporal unless the pool could stay resident
     // in the 256-MiB Infinity Cache between searches
     const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
-#define CSLAM_DMA_LAUNCH(AUX, BEST, KW)                                                           \
+#define CSLAM_DMA_LAUNCH(AUX, BEST, KW, DT)                                                         \
     do {                                                                                          \
         const size_t lds = (size_t)NW * NST * DmaGeom<KW>::kStage;                                \
         static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
         if (!attr_set[p->device & 63]) {                                                          \
-            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST, KW>, \
+            CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST, KW, DT>, \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
             attr_set[p->device & 63] = true;                                                      \
         }                                                                                         \
-        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST, KW>), dim3(blocks), dim3(NW * 64), \
+        hipLaunchKernelGGL((k_scan_dma<NS, NW, NST, AUX, BEST, KW, DT>), dim3(blocks), dim3(NW * 64), \
                            lds, st, p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Q, q_stride,    \
                            q_rows, m, dots, dots_stride, (int)n_waves,                            \
                            p->inv_norm + p->v0, (uint32_t)p->v0, cand, cand_stride, rnq_out,      \
                            split, cand_c, even);                                                  \
     } while (0)
-#define CSLAM_DMA_LAUNCH_KW(AUX, BEST)                   \
+#define CSLAM_DMA_LAUNCH_KW(AUX, BEST, DT)               \
     do {                                                 \
-        if (kw == 256) CSLAM_DMA_LAUNCH(AUX, BEST, 256); \
-        else if (kw == 128) CSLAM_DMA_LAUNCH(AUX, BEST, 128); \
-        else CSLAM_DMA_LAUNCH(AUX, BEST, 64);            \
+        if (kw == 256) CSLAM_DMA_LAUNCH(AUX, BEST, 256, DT); \
+        else if (kw == 128) CSLAM_DMA_LAUNCH(AUX, BEST, 128, DT); \
+        else CSLAM_DMA_LAUNCH(AUX, BEST, 64, DT);           \
     } while (0)
     static const char* const names[3][4] = {
         {"k_scan_dma<NS=8,NW=4,NST=2,nt,best>", "k_scan_dma<NS=8,NW=4,NST=2,best>",
@@ -1637,13 +1798,21 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
         {"k_scan_dma<NS=8,NW=4,NST=2,nt,best,KW=64>", "k_scan_dma<NS=8,NW=4,NST=2,best,KW=64>",
          "k_scan_dma<NS=8,NW=4,NST=2,nt,KW=64>", "k_scan_dma<NS=8,NW=4,NST=2,KW=64>"}};
     const int ki = kw == 256 ? 0 : (kw == 128 ? 1 : 2);
-    if (best) {
-        if (nt) CSLAM_DMA_LAUNCH_KW(2, true);
-        else CSLAM_DMA_LAUNCH_KW(0, true);
+    if (best && dots_too) {   // search with 2 <= k <= 16: composites per wave AND raw dots
+        static const char* const names_dt[3][2] = {
+            {"k_scan_dma<NS=8,NW=4,NST=2,nt,best+dots>", "k_scan_dma<NS=8,NW=4,NST=2,best+dots>"},
+            {"k_scan_dma<NS=8,NW=4,NST=2,nt,best+dots,KW=128>", "k_scan_dma<NS=8,NW=4,NST=2,best+dots,KW=128>"},
+            {"k_scan_dma<NS=8,NW=4,NST=2,nt,best+dots,KW=64>", "k_scan_dma<NS=8,NW=4,NST=2,best+dots,KW=64>"}};
+        if (nt) CSLAM_DMA_LAUNCH_KW(2, true, true);
+        else CSLAM_DMA_LAUNCH_KW(0, true, true);
+        p->last_scan_kernel = names_dt[ki][nt ? 0 : 1];
+    } else if (best) {
+        if (nt) CSLAM_DMA_LAUNCH_KW(2, true, false);
+        else CSLAM_DMA_LAUNCH_KW(0, true, false);
         p->last_scan_kernel = names[ki][nt ? 0 : 1];
     } else {
-        if (nt) CSLAM_DMA_LAUNCH_KW(2, false);
-        else CSLAM_DMA_LAUNCH_KW(0, false);
+        if (nt) CSLAM_DMA_LAUNCH_KW(2, false, false);
+        else CSLAM_DMA_LAUNCH_KW(0, false, false);
         p->last_scan_kernel = names[ki][nt ? 2 : 3];
     }
 #undef CSLAM_DMA_LAUNCH_KW
@@ -1779,11 +1948,22 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     if (knob(k_tail) && q >= 1 && tail > 0) {
         // cost in strip times (one strip through all slices): q + 1 as one launch; with the tail
         // K-split over ks parts: q + 1/ks + the extra launches (~5 us of ~10 us per chunk)
+        // A large tail (25 000 rows: 539 of 1563 strips) takes several rounds of K-split blocks -
+        // each a chunk or two of work behind ~4 us of start-up latency - and still beats a second
+        // strip for every wave: 1 + 5 rounds x (1/8 + 0.05) against 2 strip times.
         const int64_t groups = (tail + g.waves - 1) / g.waves;
-        int64_t ks = p->cus / groups;
-        ks = ks < 1 ? 1 : (ks > g.nchunks ? g.nchunks : ks);
-        const double part_cost = (double)((g.nchunks + ks - 1) / ks) / g.nchunks + 0.6 / g.nchunks;
-        if (groups <= p->cus && part_cost < 0.8) {
+        static Knob k_rounds{"CSLAM_MQ_TAIL_ROUNDS", 6};   // most rounds of tail blocks (1: round 3's first rule)
+        int64_t ks = 1;
+        double part_cost = 1e9;
+        for (int64_t k = 1; k <= g.nchunks; ++k) {   // K parts per strip group: the cheapest split
+            const int64_t r = (groups * k + p->cus - 1) / p->cus;
+            const double c = r * ((double)((g.nchunks + k - 1) / k) / g.nchunks + 0.4 / g.nchunks) + 0.2 / g.nchunks;
+            if (r <= knob(k_rounds) && c < part_cost) {
+                part_cost = c;
+                ks = k;
+            }
+        }
+        if (part_cost < 0.8) {
             g.n_main = 16 * q * waves;
             g.tail_strips = tail;
             g.tail_groups = (int)groups;
@@ -2116,7 +2296,8 @@ int append_rows_dev(cslam_pool* p, const float* rows_dev, int64_t n_rows, int64_
 // split >= 0 (window-relative row), the rows at or behind `split` apart in cand_c).  Queries are
 // read in place when they need no padding.
 int best_scan_candidates(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
-                         int64_t* stride_out, int64_t* n_cand_out, hipStream_t st) {
+                         int64_t* stride_out, int64_t* n_cand_out, hipStream_t st,
+                         float* dots = nullptr, int64_t dots_stride = 0) {
     const bool direct = p->dim == p->dp && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 &&
                         (q_stride & 3) == 0;
     const float* qsrc = q_dev;
@@ -2140,9 +2321,12 @@ int best_scan_candidates(cslam_pool* p, const float* q_dev, int64_t q_stride, in
     if (split >= 0) CSLAM_TRY(p->cand_c.reserve((size_t)16 * cstride * sizeof(uint64_t)));
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    CSLAM_TRY(launch_scan_dma(p, qsrc, qs, q_rows, m, nullptr, 0, true, p->cand_a.as<uint64_t>(),
-                              cstride, n_cand_out, st, nullptr, split,
-                              split >= 0 ? p->cand_c.as<uint64_t>() : nullptr));
+    // dots != nullptr (search with 2 <= k <= 16): the raw dots next to the composites, and the
+    // query norms the kernel used in p->rnq for the select
+    if (dots != nullptr) CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+    CSLAM_TRY(launch_scan_dma(p, qsrc, qs, q_rows, m, dots, dots_stride, true, p->cand_a.as<uint64_t>(),
+                              cstride, n_cand_out, st, dots != nullptr ? p->rnq.as<float>() : nullptr, split,
+                              split >= 0 ? p->cand_c.as<uint64_t>() : nullptr, dots != nullptr));
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
         p->prof_n++;
@@ -2222,6 +2406,21 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     int64_t chunk = m < qc ? m : qc;
     CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
     float* sims = p->sims.as<float>();
+    // <= 16 queries, 2 <= k <= 16 (lcsm.py:69's k = 10 at a handful of queries): the best-match scan
+    // that also leaves the raw dots, then ONE select launch over the rows of the k best waves
+    // instead of two select levels over every row (k_topk_from_waves).  CSLAM_TOPK_WAVES=0 keeps
+    // the two-level select.
+    static Knob k_tw{"CSLAM_TOPK_WAVES", 1};
+    if (k >= 2 && k <= kTopkWavesMaxK && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m) &&
+        (int64_t)p->cus * 4 <= kTopkWavesMax && knob(k_tw) != 0) {
+        int64_t cstride = 0, n_cand = 0;
+        CSLAM_TRY(best_scan_candidates(p, q_dev, q_stride, m, -1, &cstride, &n_cand, st, sims, sims_stride));
+        hipLaunchKernelGGL(k_topk_from_waves, dim3(m), dim3(256), 0, st, p->cand_a.as<uint64_t>(), cstride,
+                           (int)n_cand, sims, sims_stride, p->inv_norm + p->v0, p->rnq.as<float>(),
+                           (uint32_t)p->v0, p->vn, k, out_idx, out_sim);
+        CSLAM_HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     for (int q0 = 0; q0 < m; q0 += (int)qc) {
         int mb = m - q0 < (int)qc ? m - q0 : (int)qc;
         CSLAM_TRY(compute_dots(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,

@@ -10,6 +10,11 @@ if os.path.join(ROOT, "tools") not in sys.path:     # workload builders shared w
     sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 
+# the library re-reads its measurement knobs (CSLAM_TOPK_WAVES, CSLAM_MQ_TAIL, ...) at every launch
+# instead of once per process, so that a test can compare two settings in one process
+os.environ.setdefault("CSLAM_KNOBS_LIVE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

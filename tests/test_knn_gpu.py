@@ -326,6 +326,72 @@ def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("n,d,m,k", [
+    (100000, 128, 16, 10),    # lcsm.py:69's k = 10 at the reference's own descriptor length
+    (20011, 512, 5, 16),      # the largest fused k, ragged panels
+    (20011, 64, 3, 2),        # the smallest
+    (140000, 256, 9, 10),     # two panels per wave: 137 rows per wave, candidates past the register cache
+    (600000, 64, 3, 16),      # 586 rows per wave; the zero query overflows the list: arg-max rounds
+    (17, 128, 16, 16),        # two waves, k = 16 of 17 rows
+    (5, 128, 4, 10),          # k > n: the tail of every result row is (-1, -inf)
+    (1, 64, 1, 2),
+    (40000, 768, 16, 3),
+    (17000, 4096, 7, 10),     # cfg2's row shape
+])
+def test_fused_top_k_select_matches_oracle(gpu, monkeypatch, n, d, m, k):
+    """search with 2 <= k <= 16 and <= 16 queries: k_scan_dma<best+dots> + k_topk_from_waves (the rows
+    of the k best waves only) against the C oracle bit for bit, and against the two-level select
+    over every row (CSLAM_TOPK_WAVES=0).  Ties (duplicated rows, a zero query) keep the lowest row
+    first; a row window (cslam_pool_search_range_dev) selects inside the window."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(n + d + k)
+    X = (rs.rand(n, d).astype(np.float32) - 0.3)
+    if n > 300:
+        X[n // 2] = X[7]          # duplicates in different waves
+        X[n - 1] = X[7]
+        X[50] = 0.0
+    Q = rs.rand(m, d).astype(np.float32)
+    Q[0] = X[min(7, n - 1)]
+    if m > 2:
+        Q[2] = 0.0                # every similarity 0: rows 0..k-1 in order
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = mt.search_batch(Q, k)
+    assert "best+dots" in gpu.cslam_pool_scan_kernel(mt.handle).decode()
+    o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+    kk = int(o_cnt[0])
+    np.testing.assert_array_equal(rows[:, :kk], o_idx[:, :kk])
+    assert sims[:, :kk].tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    if n > 300:
+        assert list(rows[0][:3]) == [7, n // 2, n - 1][:min(k, 3)]
+    # a row window through the device-pointer API
+    lo, hi = n // 3, n - n // 5
+    if hi - lo >= 1:
+        q = torch.from_numpy(Q).cuda()
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+        sim = torch.empty((m, k), dtype=torch.float32, device="cuda")
+        rc = gpu.cslam_pool_search_range_dev(mt.handle, ctypes.c_void_p(q.data_ptr()), q.stride(0), m, k, lo, hi,
+                                             ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        w_idx, w_sim, w_cnt = oracle_knn.search(X[lo:hi], Q, k)
+        wk = int(w_cnt[0])
+        np.testing.assert_array_equal(idx.cpu().numpy()[:, :wk], w_idx[:, :wk] + lo)
+        assert sim.cpu().numpy()[:, :wk].tobytes() == w_sim[:, :wk].astype(np.float32).tobytes()
+        if wk < k:
+            assert np.all(idx.cpu().numpy()[:, wk:] == -1)
+    mt.close()
+    # the two-level select over every row gives the same bytes
+    monkeypatch.setenv("CSLAM_TOPK_WAVES", "0")
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows2, sims2 = mt.search_batch(Q, k)
+    assert "best+dots" not in gpu.cslam_pool_scan_kernel(mt.handle).decode()
+    np.testing.assert_array_equal(rows2, rows)
+    assert sims2.tobytes() == sims.tobytes()
+    mt.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
     (16384, 256, 16, 10),     # exactly the switch-over size, one 256-float slice
     (20011, 512, 5, 10),      # ragged rows: 1024 panels of 19-20 rows (partial strips everywhere)
     (17000, 4096, 3, 1),      # cfg2 row shape

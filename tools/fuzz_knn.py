@@ -25,7 +25,7 @@ for c in range(cases):
     n = int(rs.choice([1, 2, 15, 16, 17, 127, 128, 129, 1000, 4097, 16383, 16384, 20000, 33001, 70000]))
     if n * dim > 40_000_000:
         n = 40_000_000 // dim
-    m = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 64, 65, 96, 130, 300]))
+    m = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 40, 48, 64, 65, 80, 81, 96, 130, 160, 300]))
     while n * dim * m > 3_000_000_000 and m > 1:   # keep the strict-chain oracle to seconds per case
         m = max(1, m // 2)
     k = int(rs.choice([1, 2, 5, 10, 128, 129, 1000]))
@@ -56,7 +56,7 @@ for c in range(cases):
         bad += 1
         print("MISMATCH", dict(dim=dim, n=n, m=m, k=k, scale=scale, cut=cut), flush=True)
     if ok and n >= 2:
-        ms = min(m, 40)
+        ms = min(m, 100)
         hi = int(rs.randint(2, n + 1))
         split = int(rs.randint(1, hi))
         qd = torch.from_numpy(q[:ms]).cuda()

@@ -3,7 +3,7 @@ launches per shape, every result compared bit for bit with the first one (an int
 the hand-counted vmcnt / LDS-DMA pipelines would show as a flipped bit sooner or later) and the
 first one with the oracle.  Shapes cover k_scan_dma (big pool), k_scan_dma_ks (small pool, long
 descriptors), the split best-match scan, the narrow-slice variants (128 / 64 floats per slice), a ragged length
-(staged queries), the register-ring scan (dim <= 16) and k = 10."""
+(staged queries), the register-ring scan (dim <= 16), k = 10 and - round 3 - the multi-tile scan k_scan_mq."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,11 @@ bad = 0
 for (n, d, m, k, split) in [(100_000, 4096, 16, 1, -1), (100_000, 4096, 16, 1, 99_990), (3000, 4096, 16, 1, -1),
                             (20_000, 512, 16, 10, -1), (5000, 100, 7, 1, -1), (900, 2048, 3, 5, -1),
                             (400_000, 128, 16, 1, -1), (400_000, 128, 16, 1, 399_990), (300_000, 64, 16, 1, -1),
-                            (50_000, 384, 9, 10, -1), (3000, 10, 5, 3, -1)]:
+                            (50_000, 384, 9, 10, -1), (3000, 10, 5, 3, -1),
+                            # round 3: k_scan_mq (T = 2..5), plain / split / k > 1, with and without the K-split tail
+                            (100_000, 4096, 80, 1, -1), (100_000, 4096, 80, 1, 99_990), (100_000, 4096, 32, 1, -1),
+                            (25_000, 4096, 80, 1, 24_990), (60_000, 1024, 48, 1, -1), (200_000, 128, 64, 1, -1),
+                            (30_000, 512, 40, 10, -1), (7001, 192, 80, 1, -1)]:
     rs = np.random.RandomState(n + d)
     X = rs.rand(n, d).astype(np.float32); Q = rs.rand(m, d).astype(np.float32)
     pool = NearestNeighborsMatching(dim=d, capacity_hint=n); pool.add_items(X, list(range(n)))
@@ -37,7 +41,7 @@ for (n, d, m, k, split) in [(100_000, 4096, 16, 1, -1), (100_000, 4096, 16, 1, 9
         outs = tuple(o)
     run(); torch.cuda.synchronize()
     first = [t.clone() for t in outs]
-    if split < 0 and n * d * m <= 2_000_000_000:
+    if split < 0 and n * d * m <= 40_000_000_000:
         oi, os_, _ = oracle_knn.search(X, Q, k)
         assert np.array_equal(first[0].cpu().numpy(), oi) and first[1].cpu().numpy().tobytes() == os_.tobytes()
     t0 = time.perf_counter(); flips = 0
