@@ -434,7 +434,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: uniform branches
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const int w = blockIdx.x * NW + wave;
+    // wave number -> rows: block-major, or (even & 2) dealt round-robin over the blocks so that a pool
+    // of fewer strips than wave slots still puts waves on EVERY CU (a CU streams ~25-30 GB/s however
+    // many of its waves ask: 625 strips as 157 full blocks ran at 3.5 TB/s)
+    const int w = (even & 2) ? wave * (int)gridDim.x + (int)blockIdx.x : blockIdx.x * NW + wave;
     char* ring = dma_lds + wave * NST * kStage;
     const int nkc = dp / KW;
     if (w >= n_waves) return;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     // even = 1 (default): p_end equal panels; 0: panels of 128 rows, the remainder last
     const int pq = (int)((whi - wlo) / p_end), prem = (int)((whi - wlo) - (int64_t)pq * p_end);
     auto panel_lo = [&](int p) {
-        const int64_t v = even ? wlo + (int64_t)p * pq + (p < prem ? p : prem) : wlo + (int64_t)p * (16 * NS);
+        const int64_t v = (even & 1) ? wlo + (int64_t)p * pq + (p < prem ? p : prem) : wlo + (int64_t)p * (16 * NS);
         return v < whi ? v : whi;
     };
     auto panel = [&](DmaCursor& c, int p) {
@@ -752,64 +755,103 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 // k_scan_dma_ks: the scan for SMALL pools (fewer 16-row strips than CUs) and long descriptors.
 //   k_scan_dma gives a strip to one wave, which then walks all dp/256 slices one after the other
 //   with two stages in flight: at 4096-d that is 16 dependent HBM round trips for a kilobyte-sized
-//   pool (47 us for 1000 rows) while most of the chip idles.  Here a BLOCK owns the strip and its
-//   four waves split the K range: the 512-float chunks are independent fmaf chains,
-//   so wave v multiplies chunks [v c, (v+1) c) — same LDS-DMA pieces, ring and MFMA order as
-//   k_scan_dma — and leaves each chunk's partial in the LDS; after ONE barrier wave 0 folds them
-//   in chunk order (tot = ((0 + c0) + c1) + ...), exactly the sequential fold → identical bits.
+//   pool (47 us for 1000 rows) while most of the chip idles - and a CU streams ~30 GB/s only with
+//   all four of its waves asking.  Here a BLOCK owns S = 1..3 strips (an even split of the strips
+//   over min(strips, CUs) blocks) and its four waves split the S x nchunks 512-float chunks of those
+//   strips evenly, in order: the chunks are independent fmaf chains, so a wave
+//   multiplies its run of (strip, chunk) units - same LDS-DMA pieces, ring and MFMA order as
+//   k_scan_dma, the ring running across strip boundaries - and leaves each chunk's partial in the
+//   LDS; after ONE barrier wave s folds strip s in chunk order (tot = ((0 + c0) + c1) + ...),
+//   exactly the sequential fold -> identical bits.
 //   Queries are read from the staged block ([16][dp], zero padded rows); raw dots out.
+//   S > 1 only under CSLAM_SCAN_KSPLIT_STRIPS (round 3: measured, not faster than k_scan_dma for
+//   pools of 257..768 strips - ks_scan_applies; neither was a second ROUND of one-strip blocks,
+//   profiles/r03_ks_sweep.txt).
 // ---------------------------------------------------------------------------------------------
 constexpr int kKsMaxChunks = 16;   // dp <= 8192
+constexpr int kKsMaxParts = 28;    // S x nchunks partials of 1 KiB next to the 132-KiB ring
+constexpr int kKsMaxStrips = 3;    // per block
 
 template <int AUX>
 __global__ __launch_bounds__(256) void k_scan_dma_ks(const float* __restrict__ X, int64_t xs, int64_t n,
                                                      int dp, const float* __restrict__ Qstage,
                                                      int m_valid, float* __restrict__ dots,
-                                                     int64_t dots_stride) {
+                                                     int64_t dots_stride, int n_strips) {
     extern __shared__ __attribute__((aligned(16))) char ks_lds[];
     constexpr int NW = 4, NST = 2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     char* ring = ks_lds + wave * NST * kDmaStageB;
-    f32x4* part = reinterpret_cast<f32x4*>(ks_lds + NW * NST * kDmaStageB);   // [chunk][lane]
+    f32x4* part = reinterpret_cast<f32x4*>(ks_lds + NW * NST * kDmaStageB);   // [strip][chunk][lane]
     const int nkc = dp >> 8;
     const int nchunks = (nkc + 1) >> 1;
-    const int cpw = (nchunks + NW - 1) / NW;          // chunks per wave
-    const int kc0 = 2 * cpw * wave;
-    const int kc1 = min(nkc, kc0 + 2 * cpw);
-    const int64_t row_lo = (int64_t)blockIdx.x * 16;
-    int cnt = (int)(n - row_lo);                      // valid rows of the strip (>= 1)
-    cnt = cnt > 16 ? 16 : cnt;
+    // this block's strips: an even split of the strips over the blocks
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int sq = n_strips / G, srem = n_strips - sq * G;
+    const int s_first = b * sq + (b < srem ? b : srem);
+    const int S = sq + (b < srem ? 1 : 0);
+    // ... and this wave's run of (strip, chunk) units, as a run of slices [v0, v1) of the block's
+    // S x nkc slices (a chunk = two slices; the last chunk of an odd row length is one)
+    const int U = S * nchunks;
+    const int u0 = wave * U / NW, u1 = (wave + 1) * U / NW;
+    auto slice_of_unit = [&](int u) {
+        const int su = u / nchunks, cu = u - su * nchunks;
+        return su * nkc + (2 * cu < nkc ? 2 * cu : nkc);
+    };
+    const int v0 = slice_of_unit(u0), v1 = slice_of_unit(u1);
+    struct Cur { int s, kc; };
+    auto advance = [&](Cur& c) {
+        if (++c.kc == nkc) {
+            c.kc = 0;
+            ++c.s;
+        }
+    };
+    auto rows_of = [&](int sb) {   // valid rows of the block's strip sb (>= 1)
+        const int64_t left = n - (int64_t)(s_first + sb) * 16;
+        return left > 16 ? 16 : (int)left;
+    };
 
-    if (kc0 < kc1) {
-        auto issue = [&](int kc, char* slot) {
-            const float* src = X + row_lo * xs + kc * 256 + lane * 4;
+    if (v0 < v1) {
+        auto issue = [&](const Cur& c, char* slot) {
+            const int cnt = rows_of(c.s);
+            const float* src = X + (int64_t)(s_first + c.s) * 16 * xs + c.kc * 256 + lane * 4;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr)
                 if (rr < cnt)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(src + rr * xs),
                         (__attribute__((address_space(3))) void*)(slot + rr * kDmaPieceB), 16, 0, AUX);
+            return cnt;
         };
         const float* qrow = Qstage + (int64_t)r * dp + 4 * g;
+        Cur cc{v0 / nkc, v0 % nkc};   // the consumer's stage
+        Cur ci = cc;                  // the issue cursor, two stages ahead
+        const int kc_first = cc.kc;
         f32x4 bc[16], bn[16];
-        load_b16(bn, qrow + kc0 * 256);
+        load_b16(bn, qrow + cc.kc * 256);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tie16(bn);
-        issue(kc0, ring);
-        if (kc0 + 1 < kc1) issue(kc0 + 1, ring + kDmaStageB);
+        int y_next = 0;   // pieces of the stage behind the consumer's (0: none in flight)
+        issue(ci, ring);
+        advance(ci);
+        if (v0 + 1 < v1) {
+            y_next = issue(ci, ring + kDmaStageB);
+            advance(ci);
+        }
         f32x4 acc{0.f, 0.f, 0.f, 0.f};
         int slot = 0;
-        for (int kc = kc0; kc < kc1; ++kc) {
+        for (int v = v0; v < v1; ++v) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) bc[i] = bn[i];
             // ALWAYS issued (the last one re-reads the wave's first slice and is never used): an
             // asm load inside a conditional leaves the compiler free to copy its not-yet-written
             // output registers at the join
-            load_b16(bn, qrow + (kc + 1 < kc1 ? kc + 1 : kc0) * 256);
-            // younger than stage kc: stage kc+1 (if any) and the B loads just issued
-            wait_vm_dyn((kc + 1 < kc1 ? cnt : 0) + 16);
+            Cur cn = cc;
+            advance(cn);
+            load_b16(bn, qrow + (v + 1 < v1 ? cn.kc : kc_first) * 256);
+            // younger than this stage: the next stage (if any) and the B loads just issued
+            wait_vm_dyn(y_next + 16);
             char* sp = ring + slot * kDmaStageB;
             f32x4 a[16];
             const char* ap = sp + r * kDmaPieceB + g * 16;
@@ -817,28 +859,33 @@ __global__ __launch_bounds__(256) void k_scan_dma_ks(const float* __restrict__ X
             for (int i = 0; i < 16; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + i * 64);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const bool refill = kc + 2 < kc1;
-            if (refill) issue(kc + 2, sp);
+            int y_refill = 0;
+            if (v + 2 < v1) {
+                y_refill = issue(ci, sp);
+                advance(ci);
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bc[i][j], acc, 0, 0, 0);
-            if ((kc & 1) || kc + 1 == nkc) {   // end of a 512-float chunk / of the row
-                part[(kc >> 1) * 64 + lane] = acc;
+            if ((cc.kc & 1) || cc.kc + 1 == nkc) {   // end of a 512-float chunk / of the row
+                part[(cc.s * nchunks + (cc.kc >> 1)) * 64 + lane] = acc;
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            wait_vm_dyn(refill ? cnt : 0);   // the B loads have landed (only the refill is younger)
+            wait_vm_dyn(y_refill);   // the B loads have landed (only the refill is younger)
             tie16(bn);
             slot ^= 1;
+            y_next = y_refill;
+            cc = cn;
         }
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave < S) {   // wave s folds strip s
         f32x4 tot{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nchunks; ++c) tot = tot + part[c * 64 + lane];
+        for (int c = 0; c < nchunks; ++c) tot = tot + part[(wave * nchunks + c) * 64 + lane];
         if (r < m_valid) {
-            const int64_t r0 = row_lo + 4 * g;
+            const int64_t r0 = (int64_t)(s_first + wave) * 16 + 4 * g;
             float* out = dots + (int64_t)r * dots_stride + r0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1708,14 +1755,23 @@ int knob(Knob& k) {
 
 // small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
 // of a block) instead of one wave walking every slice of its strip.  CSLAM_SCAN_KSPLIT=0 keeps
-// k_scan_dma.
+// k_scan_dma.  CSLAM_SCAN_KSPLIT_STRIPS=2|3 lets a block take that many strips (pools of up to
+// 3 x CUs strips): measured SLOWER than k_scan_dma with its fused arg-max - 5000..8192 rows x
+// 4096-d 48.5 vs 45.2 us, 10 000..12 288 rows 62 vs 50 us end to end: 14 us per extra strip of a
+// block (profiles/r03_ks_strips_per_block.txt) - so the default stays one strip per block.
+int ks_strips_per_block(const cslam_pool* p) {
+    const int64_t strips = (p->vn + 15) / 16;
+    const int64_t blocks = strips < p->cus ? strips : p->cus;
+    return (int)((strips + blocks - 1) / blocks);
+}
 bool ks_scan_applies(const cslam_pool* p, int m) {
     static const bool ks_env = !(getenv("CSLAM_SCAN_KSPLIT") && atoi(getenv("CSLAM_SCAN_KSPLIT")) == 0);
     if (!ks_env || m > 16 || !dma_scan_applies(p) || p->dp % 256 != 0) return false;
-    const int64_t strips = (p->vn + 15) / 16;
     const int nchunks = (p->dp / 256 + 1) / 2;
-    static Knob k_max{"CSLAM_SCAN_KSPLIT_ROUNDS", 1};   // strips up to this many per CU take the K-split kernel
-    return strips <= (int64_t)p->cus * knob(k_max) && nchunks >= 4 && nchunks <= kKsMaxChunks;
+    static Knob k_max{"CSLAM_SCAN_KSPLIT_STRIPS", 1};
+    const int S = ks_strips_per_block(p);
+    const int cap = knob(k_max) < kKsMaxStrips ? knob(k_max) : kKsMaxStrips;
+    return S <= cap && S * nchunks <= kKsMaxParts && nchunks >= 4 && nchunks <= kKsMaxChunks;
 }
 
 // k_scan_dma over the row window [v0, v0+vn): either raw dots (best = false) or one (similarity,
@@ -1752,12 +1808,22 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     }
     if (best && cand_stride < n_waves)   // one composite per query and wave
         return fail(CSLAM_E_INVALID, "scan_dma: candidate stride");
-    const unsigned blocks = (unsigned)((n_waves + NW - 1) / NW);
+    unsigned blocks = (unsigned)((n_waves + NW - 1) / NW);
+    // one strip per wave and fewer strips than wave slots (< 16k rows): deal the waves round-robin
+    // over min(CUs, waves) blocks instead of filling block after block - 4200..10 000 rows x 4096-d:
+    // 45-48 -> 42-45 us, profiles/r03_size_sweep_spread.txt (CSLAM_SCAN_SPREAD=0: block-major as
+    // before).  NOT for the 893-wave partition of ~100k rows below: 250.5 -> 260.4 us there.
+    static Knob k_spread{"CSLAM_SCAN_SPREAD", 1};
+    int spread = 0;
+    if (knob(k_spread) != 0 && n_waves < nw && n_waves == strips && reserve_env == 0) {
+        blocks = (unsigned)(n_waves < cus_eff ? n_waves : cus_eff);
+        spread = 2;
+    }
     // a wave's rows in equal panels (default) or in panels of 128 rows and a remainder
     // (CSLAM_SCAN_EVEN_PANELS=0): fewer stage rounds (390 rows: 8 + 8
     // + 8 + 1 instead of 4 x 7) but a remainder panel pays the whole per-panel cost — equal panels
     // win or tie from 256-d to 2048-d (1024-d 0.2597 vs 0.2633 ms), lose 2 % at 128-d
-    const int even = knob(k_even) == 0 ? 0 : 1;
+    const int even = (knob(k_even) == 0 ? 0 : 1) | spread;
     // slice width: the widest of 256 / 128 / 64 floats that divides the padded row length
     const int kw = p->dp % 256 == 0 ? 256 : (p->dp % 128 == 0 ? 128 : 64);
 
@@ -1846,20 +1912,21 @@ int launch_scan(cslam_pool* p, const float* Qstage, int m, float* dots, int64_t 
         const int64_t strips = (p->vn + 15) / 16;
         const int nchunks = (p->dp / 256 + 1) / 2;
         if (rnq_out == nullptr && ks_scan_applies(p, m)) {
-            const size_t lds = (size_t)4 * 2 * kDmaStageB + (size_t)nchunks * 64 * sizeof(f32x4);
-            const bool nt = false;   // a pool this small lives in the Infinity Cache between searches
-            (void)nt;
+            const int S = ks_strips_per_block(p);
+            const size_t lds = (size_t)4 * 2 * kDmaStageB + (size_t)S * nchunks * 64 * sizeof(f32x4);
             static bool attr_set[64] = {};
             if (!attr_set[p->device & 63]) {
                 CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma_ks<0>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)((size_t)4 * 2 * kDmaStageB +
-                                                        (size_t)kKsMaxChunks * 64 * sizeof(f32x4))));
+                                                        (size_t)kKsMaxParts * 64 * sizeof(f32x4))));
                 attr_set[p->device & 63] = true;
             }
-            hipLaunchKernelGGL((k_scan_dma_ks<0>), dim3((unsigned)strips), dim3(256), lds, st,
+            // (default cache policy: a pool this small lives in the Infinity Cache between searches)
+            const unsigned blocks = (unsigned)(strips < p->cus ? strips : p->cus);
+            hipLaunchKernelGGL((k_scan_dma_ks<0>), dim3(blocks), dim3(256), lds, st,
                                p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, Qstage, m, dots,
-                               dots_stride);
+                               dots_stride, (int)strips);
             p->last_scan_kernel = "k_scan_dma_ks (K split over the block's waves)";
         } else if (use_dma) {
             int64_t n_panels = 0;

@@ -673,11 +673,20 @@ def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     (333, 8192, 7, 400),       # 16 chunks, k > n
     (50, 3072, 16, 1),         # 6 chunks: two waves with two, one with... none for the last
     (640, 2304, 3, 5),         # odd number of slices (9): the last chunk is half a chunk
+    # CSLAM_SCAN_KSPLIT_STRIPS=3: up to three strips per block, the waves' runs of chunks cross strip boundaries
+    (5000, 4096, 16, 1),       # 313 strips on 256 blocks: 57 blocks with two strips
+    (8192, 4096, 7, 10),       # two strips for every block: each wave a half strip
+    (10007, 4096, 16, 1),      # 626 strips, the last with 7 rows: blocks of two and three strips
+    (12288, 4096, 3, 1),       # three strips for every block: 24 chunks, six per wave
+    (9000, 2304, 16, 4),       # three strips x 5 chunks (the last one slice only): runs of 3/4/4/4 chunks
+    (6000, 1792, 5, 1),        # 7 slices = 4 chunks, the last a single slice; two strips per block
+    (7000, 8192, 2, 1),        # 16 chunks: 438 strips would need two strips = 32 partials per block: k_scan_dma
 ])
-def test_small_pool_k_split_scan_is_bit_identical(gpu, n, d, m, k):
-    """k_scan_dma_ks (pools with fewer strips than CUs, descriptors of >= 4 chunks): the waves of
-    a block split the K range at chunk granularity and wave 0 folds the chunk partials in order —
-    bit-identical to the oracle's sequential fold."""
+def test_small_pool_k_split_scan_is_bit_identical(gpu, monkeypatch, n, d, m, k):
+    """k_scan_dma_ks (pools of up to three strips per CU, descriptors of >= 4 chunks): the waves of
+    a block split the chunks of the block's strips evenly and wave s folds the chunk partials of
+    strip s in order — bit-identical to the oracle's sequential fold."""
+    monkeypatch.setenv("CSLAM_SCAN_KSPLIT_STRIPS", "3")   # default 1: more strips per block measured slower
     rs = np.random.RandomState(n + d + m + k)
     X = (rs.rand(n, d).astype(np.float32) - 0.3)
     Q = rs.rand(m, d).astype(np.float32) - 0.3
@@ -685,7 +694,8 @@ def test_small_pool_k_split_scan_is_bit_identical(gpu, n, d, m, k):
     Q[0] = X[0]
     pool = _pool(gpu, X, dim=d, capacity_hint=n)
     rows, sims = pool.search_batch(Q, k)
-    assert gpu.cslam_pool_scan_kernel(pool.handle).decode().startswith("k_scan_dma_ks")
+    kernel = gpu.cslam_pool_scan_kernel(pool.handle).decode()
+    assert kernel.startswith("k_scan_dma<" if (n, d) == (7000, 8192) else "k_scan_dma_ks"), kernel
     o_idx, o_sim, _ = oracle_knn.search(X, Q, k)
     kk = min(k, n)
     np.testing.assert_array_equal(rows, o_idx[:, :kk])
