@@ -2012,7 +2012,10 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     g.n_main = p->vn;
     const int64_t waves = (int64_t)g.waves * g.n_blocks;
     const int64_t q = strips / waves, tail = strips - q * waves;
-    if (knob(k_tail) && q >= 1 && tail > 0) {
+    // q == 0: fewer strips than waves - one strip per wave leaves CUs idle and every wave walks
+    // the whole K range alone (5000 rows x 80 queries: 117 us, as long as 16 000 rows); the whole
+    // pool then goes the tail's way when the K split pays
+    if (knob(k_tail) && tail > 0) {
         // cost in strip times (one strip through all slices): q + 1 as one launch; with the tail
         // K-split over ks parts: q + 1/ks + the extra launches (~5 us of ~10 us per chunk)
         // A large tail (25 000 rows: 539 of 1563 strips) takes several rounds of K-split blocks -
@@ -2030,7 +2033,7 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
                 ks = k;
             }
         }
-        if (part_cost < 0.8) {
+        if (part_cost < (q >= 1 ? 0.8 : 0.85)) {
             g.n_main = 16 * q * waves;
             g.tail_strips = tail;
             g.tail_groups = (int)groups;
@@ -2039,7 +2042,7 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     }
     const int64_t strips_main = (g.n_main + 15) / 16;
     const int64_t strips_max = (strips_main + g.n_blocks - 1) / g.n_blocks;   // blocks take whole strips
-    g.p_max = (int)((strips_max + g.waves * ns - 1) / (g.waves * ns));
+    g.p_max = (int)((strips_max + g.waves * ns - 1) / (g.waves * ns));   // 0: everything in the K-split launch
     g.n_cand = (int64_t)g.n_blocks * g.p_max * g.waves + g.tail_strips;
     g.nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
     return g;
@@ -2093,7 +2096,8 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         CSLAM_TRY(p->part.reserve((size_t)g.tail_strips * g.nchunks * g.tiles * 64 * sizeof(f32x4)));
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    CSLAM_TRY(launch_scan_mq(a, g.tiles, g.kw, g.waves, best ? kMqModeBest : kMqModeDots, g.nt, st));
+    if (g.n_main > 0)
+        CSLAM_TRY(launch_scan_mq(a, g.tiles, g.kw, g.waves, best ? kMqModeBest : kMqModeDots, g.nt, st));
     if (g.tail_strips > 0) {
         // the tail window [n_main, vn): K-split launch, then the fold + epilogue of its strips
         MqArgs b = a;
