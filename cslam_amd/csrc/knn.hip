@@ -2033,7 +2033,11 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
                 ks = k;
             }
         }
-        if (part_cost < (q >= 1 ? 0.8 : 0.85)) {
+        // percent of a strip time the split may cost: the model is optimistic about multi-round tails -
+        // at 90 / 100 the 25 000-row pool's 80-query pass goes 207 -> 216 us, 60 000 rows 368 -> 381
+        // (profiles/r03_mq_tail_cost_ab.txt)
+        static Knob k_cost{"CSLAM_MQ_TAIL_MAXCOST", 80};
+        if (part_cost < (q >= 1 ? knob(k_cost) * 0.01 : 0.85)) {
             g.n_main = 16 * q * waves;
             g.tail_strips = tail;
             g.tail_groups = (int)groups;
