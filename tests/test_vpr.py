@@ -160,3 +160,35 @@ def test_descriptors_flow_from_head_to_pool_without_host(gpu):
     assert [tuple(e) for e in got] == [tuple(e) for e in want]
     np.testing.assert_array_equal(np.asarray(a.local_nnsm.data), np.asarray(b.local_nnsm.data))
     assert a.candidate_selector.candidate_edges.keys() == b.candidate_selector.candidate_edges.keys()
+
+
+@pytest.mark.gpu
+def test_heads_on_the_gpu_match_the_reference_layers(gpu):
+    """The aggregation heads run on the GPU (PyTorch-ROCm) in the product: CosPlace's L2Norm / GeM /
+    Linear / L2Norm and both NetVLAD variants on cuda:0 against the outputs of the REFERENCE's own
+    layer classes (tests/golden/vpr_ref.npz, gen_golden.gen_vpr) - not against this package's CPU
+    path.  fp32 on rocBLAS / MIOpen in another association order: 5e-6 on unit-norm outputs."""
+    from cslam_amd.vpr.layers import Flatten, GeM, L2Norm, NetVLADLayer
+    dev = torch.device("cuda:0")
+    fc = torch.nn.Linear(96, 40).to(dev)
+    gem = GeM().to(dev)
+    with torch.no_grad():
+        fc.weight.copy_(torch.from_numpy(G["cos_fc_w"]))
+        fc.bias.copy_(torch.from_numpy(G["cos_fc_b"]))
+        gem.p.fill_(float(G["cos_p"]))
+        x = torch.from_numpy(G["cos_feats"]).to(dev)
+        pooled = torch.nn.Sequential(L2Norm(), gem, Flatten())(x)
+        out = torch.nn.Sequential(L2Norm(), gem, Flatten(), fc, L2Norm())(x)
+    assert out.is_cuda
+    np.testing.assert_allclose(pooled.cpu().numpy(), G["cos_gem"], rtol=5e-5, atol=1e-7)
+    np.testing.assert_allclose(out.cpu().numpy(), G["cos_out"], rtol=0, atol=5e-6)
+    for tag, v2 in (("v1", False), ("v2", True)):
+        layer = NetVLADLayer(num_clusters=6, dim=24, vladv2=v2).eval().to(dev)
+        with torch.no_grad():
+            layer.conv.weight.copy_(torch.from_numpy(G[f"vlad_{tag}_conv_w"]))
+            if v2:
+                layer.conv.bias.copy_(torch.from_numpy(G[f"vlad_{tag}_conv_b"]))
+            layer.centroids.copy_(torch.from_numpy(G[f"vlad_{tag}_centroids"]))
+            got = layer(torch.from_numpy(G[f"vlad_{tag}_x"]).to(dev))
+        assert got.is_cuda
+        np.testing.assert_allclose(got.cpu().numpy(), G[f"vlad_{tag}_out"], rtol=0, atol=5e-6)
