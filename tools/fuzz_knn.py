@@ -22,13 +22,13 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
     dim = int(rs.choice([1, 3, 16, 17, 64, 100, 120, 128, 192, 255, 256, 320, 384, 511, 512, 640, 1000, 1024, 2048, 4096]))
-    n = int(rs.choice([1, 2, 15, 16, 17, 127, 128, 129, 1000, 4097, 16383, 16384, 20000, 33001, 70000]))
+    n = int(rs.choice([1, 2, 15, 16, 17, 127, 128, 129, 1000, 4097, 8192, 12000, 16383, 16384, 20000, 33001, 70000]))
     if n * dim > 40_000_000:
         n = 40_000_000 // dim
     m = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 40, 48, 64, 65, 80, 81, 96, 130, 160, 300]))
     while n * dim * m > 3_000_000_000 and m > 1:   # keep the strict-chain oracle to seconds per case
         m = max(1, m // 2)
-    k = int(rs.choice([1, 2, 5, 10, 128, 129, 1000]))
+    k = int(rs.choice([1, 1, 2, 3, 5, 10, 16, 17, 128, 129, 1000]))
     scale = float(rs.choice([1.0, 1e-3, 1e3]))
     x = (rs.rand(n, dim).astype(np.float32) - (0.5 if rs.rand() < 0.5 else 0.0)) * scale
     if n > 4:
