@@ -419,6 +419,15 @@ def test_fused_top_k_select_matches_oracle(gpu, monkeypatch, n, d, m, k):
     (7001, 192, 16, 1),       # three slices
     (7001, 320, 3, 7),        # five slices
     (4000, 576, 11, 1),       # nine slices: 512 + 64
+    # mid-size pools at the benchmark's row length (configs[3]: 25 000 keyframes per robot): one or
+    # two strips per wave, ragged splits
+    (20000, 4096, 16, 1),     # 1250 strips on 1024 waves: 19.5 rows per wave
+    (25000, 4096, 16, 1),     # cfg4's pool
+    (25000, 4096, 16, 10),    # ... with the fused top-k select
+    (40000, 4096, 5, 1),      # 39 rows per wave: three stages per slice
+    (60000, 4096, 16, 1),     # 58.6 rows per wave
+    (5000, 4096, 16, 1),      # one strip per wave, waves dealt round-robin over the CUs
+    (9000, 4096, 3, 10),      # ... 563 strips: two or three waves per CU
 ])
 def test_dma_scan_matches_oracle(gpu, n, d, m, k):
     """k_scan_dma (the default scan for <= 16 queries; slice width 256 / 128 / 64 floats) against the C
