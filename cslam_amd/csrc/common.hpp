@@ -106,8 +106,18 @@ struct BestCandidates {
     const uint64_t* c = nullptr;  // ... of rows >= split
     int64_t stride = 0, n = 0;
 };
+// staged = the block pool_stage_queries_on() left for these m queries (17..80: the multi-tile scan then
+// skips its own staging launch), or nullptr
 int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
                                int64_t split_row, int64_t row_hi, hipStream_t st,
-                               BestCandidates* out, bool* applied);
+                               BestCandidates* out, bool* applied, const float* staged = nullptr,
+                               const float* staged_rnq = nullptr);
+// The multi-tile scan reads its queries from a zero-padded block [16 ceil(m / 16)][padded dim] next to
+// their inverse norms.  A caller that has the queries a step early (the shard: the exchange lands while
+// the previous step is being scanned) stages them on ITS stream into buffers of its own.
+int pool_mq_free_cus(const cslam_pool_t* p, int m, int64_t rows);   // CUs that scan leaves to other streams
+int64_t pool_staged_floats(const cslam_pool_t* p, int m);   // floats of the staged block (norms: 16 ceil(m / 16))
+int pool_stage_queries_on(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
+                          float* staged, float* staged_rnq, hipStream_t st);
 
 }  // namespace cslam

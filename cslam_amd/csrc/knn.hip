@@ -1995,7 +1995,9 @@ struct MqPlan {
     int64_t n_cand;      // composites per query (best-match mode)
     bool nt;
 };
-MqPlan mq_plan(const cslam_pool* p, int m) {
+// (rows >= 0: plan for a window of that many rows instead of the current one)
+MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1) {
+    const int64_t vn = rows >= 0 ? rows : p->vn;
     static Knob k_tail{"CSLAM_MQ_TAIL", 1};
     MqPlan g{};
     g.tiles = (m + 15) / 16;
@@ -2006,10 +2008,10 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
     if (g.waves == 8) g.kw = 64;                // eight private rings fit the LDS with 4-KiB stages only
     g.nchunks = (p->dp + 511) / 512;
     const int ns = mq_panel_strips(g.tiles, g.waves);
-    const int64_t strips = (p->vn + 15) / 16;
+    const int64_t strips = (vn + 15) / 16;
     const int64_t want = (strips + g.waves - 1) / g.waves;   // a strip per wave at least
     g.n_blocks = (int)(want < p->cus ? (want < 1 ? 1 : want) : p->cus);
-    g.n_main = p->vn;
+    g.n_main = vn;
     const int64_t waves = (int64_t)g.waves * g.n_blocks;
     const int64_t q = strips / waves, tail = strips - q * waves;
     // q == 0: fewer strips than waves - one strip per wave leaves CUs idle and every wave walks
@@ -2045,10 +2047,22 @@ MqPlan mq_plan(const cslam_pool* p, int m) {
         }
     }
     const int64_t strips_main = (g.n_main + 15) / 16;
+    // A wave's time is its number of whole strips: 1563 strips need two per wave on 256 CUs (6 or 7 per
+    // block) and STILL two per wave on 196 CUs (8 per block).  Just enough blocks for that many strips per
+    // wave: the makespan is the same and the other CUs stay free for what the caller runs beside the scan -
+    // the exchange stream's pack / append / unpack kernels and a collective's own kernel, which cannot
+    // share a CU with a scan block (512 registers per lane, 144 KiB of LDS) and otherwise pile up in
+    // front of the next scan.  CSLAM_MQ_PACK_BLOCKS=0: one block per CU whenever there are strips for it.
+    static Knob k_pack{"CSLAM_MQ_PACK_BLOCKS", 1};
+    if (knob(k_pack) && strips_main > 0 && g.tiles >= 3) {   // (two tiles lean on the HBM: 4-6 % slower on fewer CUs)
+        const int64_t per_wave = (strips_main + (int64_t)g.waves * g.n_blocks - 1) / ((int64_t)g.waves * g.n_blocks);
+        const int64_t blocks = (strips_main + g.waves * per_wave - 1) / (g.waves * per_wave);
+        if (blocks >= 1 && blocks < g.n_blocks) g.n_blocks = (int)blocks;
+    }
     const int64_t strips_max = (strips_main + g.n_blocks - 1) / g.n_blocks;   // blocks take whole strips
     g.p_max = (int)((strips_max + g.waves * ns - 1) / (g.waves * ns));   // 0: everything in the K-split launch
     g.n_cand = (int64_t)g.n_blocks * g.p_max * g.waves + g.tail_strips;
-    g.nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
+    g.nt = (size_t)vn * p->xs * sizeof(float) > ((size_t)192 << 20);
     return g;
 }
 const char* mq_name(const MqPlan& g, bool best) {
@@ -2069,20 +2083,23 @@ const char* mq_name(const MqPlan& g, bool best) {
 }
 // stage `m` queries (17..80) and scan the window [v0, v0 + vn): raw dots, or (best) one composite
 // per query and panel in cand (and cand_c behind `split`, window-relative, when given)
+// (staged != nullptr: the caller staged the queries itself - pool_stage_queries_on - with their norms in rnq)
 int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* rnq, float* dots,
             int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride, int64_t split,
-            uint64_t* cand_c, const MqPlan& g, hipStream_t st) {
+            uint64_t* cand_c, const MqPlan& g, hipStream_t st, const float* staged = nullptr) {
     const int mq_pad = 16 * g.tiles;
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim, m,
-                       mq_pad, p->dp, p->qstage.as<float>(), rnq, vec_ok, (int64_t)0);
-    CSLAM_HIP_TRY(hipGetLastError());
+    if (staged == nullptr) {
+        const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim, m,
+                           mq_pad, p->dp, p->qstage.as<float>(), rnq, vec_ok, (int64_t)0);
+        CSLAM_HIP_TRY(hipGetLastError());
+    }
     MqArgs a{};
     a.X = p->rows + p->v0 * p->xs;
     a.xs = p->xs;
     a.n = g.n_main;
     a.dp = p->dp;
-    a.Q = p->qstage.as<float>();
+    a.Q = staged != nullptr ? staged : p->qstage.as<float>();
     a.rnq = rnq;
     a.m_valid = m;
     a.dots = dots;
@@ -2919,9 +2936,31 @@ int pool_order_on(cslam_pool_t* p, hipStream_t st) {
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     return mark_dev(p, st);
 }
+// CUs a multi-tile scan of `m` queries over `rows` rows leaves to other streams (0: none, or another kernel)
+int pool_mq_free_cus(const cslam_pool_t* p, int m, int64_t rows) {
+    if (!p || rows <= 0 || m <= 16 || m > 16 * mq_max_tiles() || p->dp % 64 != 0) return 0;
+    const MqPlan g = mq_plan(p, m, rows);
+    return g.tail_strips == 0 && g.n_main > 0 ? p->cus - g.n_blocks : 0;
+}
+int64_t pool_staged_floats(const cslam_pool_t* p, int m) {
+    return p && m > 0 ? (int64_t)((m + 15) / 16 * 16) * p->dp : 0;
+}
+int pool_stage_queries_on(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
+                          float* staged, float* staged_rnq, hipStream_t st) {
+    if (!p || !queries_dev || !staged || !staged_rnq || m < 1 || query_stride < p->dim)
+        return fail(CSLAM_E_INVALID, "pool_stage_queries_on: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    const int mq_pad = (m + 15) / 16 * 16;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(queries_dev) & 15) == 0 && (query_stride & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, queries_dev, query_stride, p->dim, m,
+                       mq_pad, p->dp, staged, staged_rnq, vec_ok, (int64_t)0);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
 int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
                                int64_t split_row, int64_t row_hi, hipStream_t st,
-                               BestCandidates* out, bool* applied) {
+                               BestCandidates* out, bool* applied, const float* staged,
+                               const float* staged_rnq) {
     *applied = false;
     if (!p || m < 1 || m > 16 * mq_max_tiles() || split_row <= 0 || split_row >= row_hi || row_hi > p->n ||
         !queries_dev || query_stride < p->dim)
@@ -2938,8 +2977,11 @@ int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_
         const int64_t cstride = (g.n_cand + 63) / 64 * 64;
         CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
         CSLAM_TRY(p->cand_c.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
-        CSLAM_TRY(mq_pass(p, queries_dev, query_stride, m, p->rnq.as<float>(), nullptr, 0, true,
-                          p->cand_a.as<uint64_t>(), cstride, split_row, p->cand_c.as<uint64_t>(), g, st));
+        const bool pre = staged != nullptr && staged_rnq != nullptr;
+        CSLAM_TRY(mq_pass(p, queries_dev, query_stride, m,
+                          pre ? const_cast<float*>(staged_rnq) : p->rnq.as<float>(), nullptr, 0, true,
+                          p->cand_a.as<uint64_t>(), cstride, split_row, p->cand_c.as<uint64_t>(), g, st,
+                          pre ? staged : nullptr));
         out->a = p->cand_a.as<uint64_t>();
         out->c = p->cand_c.as<uint64_t>();
         out->stride = cstride;

@@ -241,6 +241,9 @@ struct Slot {
     float* topk_sim = nullptr;
     int32_t *idx_a = nullptr, *idx_c = nullptr;   // bulk mode
     float *sim_a = nullptr, *sim_c = nullptr;
+    float* staged = nullptr;          // best2, 17..80 gathered descriptors: the multi-tile scan's query block
+    float* staged_rnq = nullptr;      // ... and inverse norms, staged at publish time on the exchange stream
+    bool staged_valid = false;        // this step's block was staged at publish time
     cslam_match_record_t* recs_all = nullptr;     // [R][3*R*b_max]  (own part at index me)
     cslam_match_record_t* recs_host = nullptr;    // pinned copy
     hipEvent_t ev_src = nullptr, ev_pub = nullptr, ev_match = nullptr, ev_done = nullptr;
@@ -360,6 +363,13 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
         A(dalloc(&s.all_rows, M * sh->dim));
         A(dalloc(&s.all_meta, (size_t)nb_robots * (1 + max_block)));
         A(dalloc(&s.recs_all, (size_t)nb_robots * sh->rec_slots));
+        static const bool prestage = !(getenv("CSLAM_SHARD_PRESTAGE") && atoi(getenv("CSLAM_SHARD_PRESTAGE")) == 0);
+        if (sh->best2 && M > 16 && prestage) {
+            // the gathered block is staged for the multi-tile scan as soon as it has landed (publish), on
+            // the exchange stream: the staging launch leaves the matching stream's critical path
+            A(dalloc(&s.staged, (size_t)pool_staged_floats(pool, (int)M)));
+            A(dalloc(&s.staged_rnq, (size_t)((M + 15) / 16 * 16)));
+        }
         if (sh->fused && !sh->best2) {
             A(dalloc(&s.topk_idx, M * sh->K));
             A(dalloc(&s.topk_sim, M * sh->K));
@@ -395,7 +405,8 @@ int cslam_shard_destroy(cslam_shard_t* sh) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kSlots; ++i) {
         Slot& s = sh->slot[i];
-        for (void* p : {(void*)s.pack, (void*)s.all_rows, (void*)s.all_meta, (void*)s.topk_idx, (void*)s.topk_sim,
+        for (void* p : {(void*)s.pack, (void*)s.all_rows, (void*)s.all_meta, (void*)s.staged, (void*)s.staged_rnq,
+                        (void*)s.topk_idx, (void*)s.topk_sim,
                         (void*)s.idx_a, (void*)s.idx_c, (void*)s.sim_a, (void*)s.sim_c,
                         (void*)s.recs_all})
             if (p) (void)hipFree(p);
@@ -474,6 +485,14 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
                            dim, s.all_rows, s.all_meta);
         CSLAM_HIP_TRY(hipGetLastError());
     }
+    // Stage the gathered block for the multi-tile scan here, on the exchange stream - but only when that
+    // scan leaves CUs free: a scan block fills a CU (registers and LDS), so beside a scan on every CU the
+    // staging kernel would only queue up in front of the NEXT scan, where it costs more than on the
+    // matching stream itself (cfg4, 25 000 rows: 0.216 ms per step with 60 CUs free, 0.267-0.297 without
+    // them against 0.245; profiles/r03_shard_pack_prestage_ab.txt)
+    s.staged_valid = s.staged != nullptr && pool_mq_free_cus(sh->pool, R * bm, s.n0 + b) >= 16;
+    if (s.staged_valid)
+        CSLAM_TRY(pool_stage_queries_on(sh->pool, s.all_rows, dim, R * bm, s.staged, s.staged_rnq, ps));
     CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, ps));
     s.b = b;
     s.step = sh->pub_step++;
@@ -511,7 +530,9 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         // descriptor; its candidates are reduced by the record kernel itself
         BestCandidates bc;
         bool applied = false;
-        CSLAM_TRY(pool_best_split_candidates(sh->pool, s.all_rows, dim, M, n0, hi, st, &bc, &applied));
+        CSLAM_TRY(pool_best_split_candidates(sh->pool, s.all_rows, dim, M, n0, hi, st, &bc, &applied,
+                                             s.staged_valid ? s.staged : nullptr,
+                                             s.staged_valid ? s.staged_rnq : nullptr));
         if (applied) {
             hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, me, R, bm,
                                s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, bc.a, bc.c, bc.stride, bc.n,
