@@ -14,13 +14,14 @@ Workload (configs[1], fits one GPU): every rank is one robot holding a resident 
           (cslam_amd.multi_robot.DeviceShard → csrc/shard.hip, csrc/comm.hip): every rank
           publishes 16/N new descriptors, ONE RCCL all-gather of the blocks + keyframe ids, the own
           block is appended to the pool, ONE scan launch of the pool for all 16 gathered descriptors
-          (best old row and best row of the new block: inter-robot match, lcsm.py:58-76 / 37-56;
-          intra-robot matching off as in the node's defaults, CSLAM_BENCH_INTRA=1 turns it on),
+          (foreign descriptors: best old row and best row of the new block, the inter-robot match of
+          lcsm.py:58-76 / 37-56; the rank's own ones: match_local_loop_closures, lcsm.py:78-97, with
+          nb_best_matches = 10 - frontend.enable_intra_robot_loop_closures on, so that every gathered
+          descriptor is a candidate evaluation exactly as the 16 own ones are at N = 1;
+          CSLAM_BENCH_INTRA=0 leaves the own ones out and counts the 16 (N-1)/N foreign ones only),
           20-byte match records built on the device, ONE RCCL all-gather of the records, records
           fetched by the host.  Per-GPU work fixed as N grows (weak scaling): 16 descriptors scanned
-          per rank and step, of which the 16 (N-1)/N FOREIGN ones are inter-robot best-match
-          evaluations (the own ones are skipped by the record kernel): value = N * 16 (N-1)/N /
-          step time (all 16 count with CSLAM_BENCH_INTRA=1).  The exchange of step t+1 is issued
+          and matched per rank and step: value = N * 16 / step time.  The exchange of step t+1 is issued
           before the scan of step t, records are fetched one step late.  Control plane (barriers,
           max over ranks, communicator id): a gloo process group; the only GPU collectives are the
           library's own RCCL communicator (ONE, shared by both exchanges).
@@ -191,7 +192,12 @@ def main():
 
     dist_info = None
     state = {"published": 0, "matched": 0, "fetched": 0, "records": 0}
-    intra = os.environ.get("CSLAM_BENCH_INTRA") == "1"
+    # cfg2 protocol at N > 1: the rank's OWN new descriptors are matched too (intra-robot matching,
+    # match_local_loop_closures, nb_best_matches = 10) - every one of the 16 gathered descriptors is a
+    # candidate evaluation, as at N = 1, so the per-GPU work AND the per-GPU count are fixed as N grows.
+    # cfg4: inter-robot matching only, the node's default.  CSLAM_BENCH_INTRA=0/1 overrides either.
+    intra_env = os.environ.get("CSLAM_BENCH_INTRA")
+    intra = (not cfg4) if intra_env is None else intra_env == "1"
     if nb_robots == 1:
         def step(t):
             search(new_local, 1, out_idx, out_sim)
@@ -339,9 +345,10 @@ def main():
         where = ("RCCL all-gather" if world > 1 else "loopback all-gather (one GPU, robot 0 of %d)" % nb_robots)
         workload = (("cfg4: %d keyframes x %d-d per robot, " % (N, D) if cfg4 else "cfg2 pool per GPU under the cfg4 protocol: ") +
                     f"every robot publishes {per_rank} new descriptors per step, ONE {where} of blocks + ids, append, "
-                    f"one scan of the pool for all {gathered_rows} gathered descriptors (inter-robot match: best old "
-                    "row + best new row), match records built on the device, one all-gather of the records, "
-                    "fetched by the host")
+                    f"one scan of the pool for all {gathered_rows} gathered descriptors (" +
+                    ("foreign ones: inter-robot best match; own ones: intra-robot match with nb_best_matches = 10"
+                     if intra else "inter-robot match: best old row + best new row") +
+                    "), match records built on the device, one all-gather of the records, fetched by the host")
     # more than two query tiles: the scan is bound by the fp32 matrix pipe, not by HBM
     mfma_bound = gathered_rows > 32
     roofline = {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved,

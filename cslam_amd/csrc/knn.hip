@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_topk_from_waves: exact top-k (2 <= k <= 16) of ONE query per block from what the fused scan left:
+// k_topk_from_waves: exact top-k (2 <= k <= 32) of ONE query per block from what the fused scan left:
 // the best (similarity, row) composite of every wave (cand) and the raw dots of every row.
 //   The k-th best row is at least as good as the k-th best WAVE maximum (k distinct waves hold k
 //   distinct rows that good), and a wave whose maximum is below it holds no row of the top k: the
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
 //   B2  rank inside the list = output position.  A list overflow (> 1024 rows at or above the
 //       bound: an all-zero query over waves of > 64 rows) takes k rounds of block arg-max instead.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTopkWavesMaxK = 16;
+constexpr int kTopkWavesMaxK = 32;   // (the shard's fused intra + inter search asks for block + nb_best_matches <= 26)
 constexpr int kTopkWavesMax = 1024;   // scan waves (= 4 x CUs at most) and list entries
 __global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restrict__ cand, int64_t cand_stride,
                                                          int n_waves, const float* __restrict__ dots,
@@ -2498,7 +2498,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     int64_t chunk = m < qc ? m : qc;
     CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
     float* sims = p->sims.as<float>();
-    // <= 16 queries, 2 <= k <= 16 (lcsm.py:69's k = 10 at a handful of queries): the best-match scan
+    // <= 16 queries, 2 <= k <= 32 (lcsm.py:69's k = 10 at a handful of queries): the best-match scan
     // that also leaves the raw dots, then ONE select launch over the rows of the k best waves
     // instead of two select levels over every row (k_topk_from_waves).  CSLAM_TOPK_WAVES=0 keeps
     // the two-level select.

@@ -47,11 +47,17 @@ def test_bench_self_launches_two_ranks(gpu):
     assert dist["world_size"] == 2 and dist["control_plane_backend"] == "gloo" and dist["communicators"] == 1
     # ONE all-gather of blocks + ids at publish time, ONE of the records at match time
     assert dist["new_descriptors_per_rank_per_step"] == 8 and abs(dist["collectives_per_step"] - 2) < 0.5
-    # threshold 0 on non-negative data: every foreign descriptor matches its best old row
-    assert dist["match_records_per_step"] >= 16
+    # threshold 0 on non-negative data: every foreign descriptor matches its best old row, every own
+    # one its intra-robot match (the cfg2 protocol's default: all 16 gathered descriptors are evaluated)
+    assert dist["match_records_per_step"] >= 2 * 16
     assert dist["allgather_payload_bytes_per_step"] > 2 * 8 * 256 * 4
-    # only the FOREIGN descriptors are inter-robot evaluations: 8 of the 16 gathered ones per rank
-    assert d["config"]["evaluations_per_step_per_gpu"] == 8
+    assert d["config"]["evaluations_per_step_per_gpu"] == 16
+    assert abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "best+dots" in d["roofline"]["kernel"]        # one fused scan: composites per wave + dots, K = 8 + 10
+    # inter-robot matching only: the FOREIGN descriptors are the evaluations, 8 of the 16 gathered per rank
+    d = _run(["--gpus", "2", "--keyframes", "6000", "--dim", "256", "--steps", "6", "--warmup", "2"],
+             {"CSLAM_BENCH_SAME_DEVICE": "1", "CSLAM_BENCH_BACKEND": "gloo", "CSLAM_BENCH_INTRA": "0"})
+    assert d["config"]["evaluations_per_step_per_gpu"] == 8 and d["dist"]["match_records_per_step"] >= 16
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["roofline"]["kernel"].endswith("best>")     # the split best-match scan ran
 

@@ -327,7 +327,9 @@ def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
 
 @pytest.mark.parametrize("n,d,m,k", [
     (100000, 128, 16, 10),    # lcsm.py:69's k = 10 at the reference's own descriptor length
-    (20011, 512, 5, 16),      # the largest fused k, ragged panels
+    (20011, 512, 5, 16),      # ragged panels
+    (20011, 512, 16, 18),     # the sharded step's fused search at two robots: block of 8 + nb_best_matches 10
+    (100000, 128, 9, 32),     # the largest fused k
     (20011, 64, 3, 2),        # the smallest
     (140000, 256, 9, 10),     # two panels per wave: 137 rows per wave, candidates past the register cache
     (600000, 64, 3, 16),      # 586 rows per wave; the zero query overflows the list: arg-max rounds
@@ -338,7 +340,7 @@ def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
     (17000, 4096, 7, 10),     # cfg2's row shape
 ])
 def test_fused_top_k_select_matches_oracle(gpu, monkeypatch, n, d, m, k):
-    """search with 2 <= k <= 16 and <= 16 queries: k_scan_dma<best+dots> + k_topk_from_waves (the rows
+    """search with 2 <= k <= 32 and <= 16 queries: k_scan_dma<best+dots> + k_topk_from_waves (the rows
     of the k best waves only) against the C oracle bit for bit, and against the two-level select
     over every row (CSLAM_TOPK_WAVES=0).  Ties (duplicated rows, a zero query) keep the lowest row
     first; a row window (cslam_pool_search_range_dev) selects inside the window."""
