@@ -1996,7 +1996,7 @@ struct MqPlan {
     bool nt;
 };
 // (rows >= 0: plan for a window of that many rows instead of the current one)
-MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1) {
+MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller = -1) {
     const int64_t vn = rows >= 0 ? rows : p->vn;
     static Knob k_tail{"CSLAM_MQ_TAIL", 1};
     MqPlan g{};
@@ -2054,7 +2054,11 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1) {
     // share a CU with a scan block (512 registers per lane, 144 KiB of LDS) and otherwise pile up in
     // front of the next scan.  CSLAM_MQ_PACK_BLOCKS=0: one block per CU whenever there are strips for it.
     static Knob k_pack{"CSLAM_MQ_PACK_BLOCKS", 1};
-    if (knob(k_pack) && strips_main > 0 && g.tiles >= 3) {   // (two tiles lean on the HBM: 4-6 % slower on fewer CUs)
+    // Two tiles lean on the HBM and lose 4-6 % of kernel time on fewer CUs: packed only for the shard's
+    // own searches, where the exchange stream's kernels beside the scan are worth more (30 gathered
+    // descriptors x 25 000 rows: 0.131-0.133 -> 0.126-0.127 ms per step), or with CSLAM_MQ_PACK_BLOCKS=2.
+    const bool shard = shard_caller >= 0 ? shard_caller != 0 : p->internal_caller;
+    if (knob(k_pack) && strips_main > 0 && (g.tiles >= 3 || shard || knob(k_pack) == 2)) {
         const int64_t per_wave = (strips_main + (int64_t)g.waves * g.n_blocks - 1) / ((int64_t)g.waves * g.n_blocks);
         const int64_t blocks = (strips_main + g.waves * per_wave - 1) / (g.waves * per_wave);
         if (blocks >= 1 && blocks < g.n_blocks) g.n_blocks = (int)blocks;
@@ -2939,7 +2943,7 @@ int pool_order_on(cslam_pool_t* p, hipStream_t st) {
 // CUs a multi-tile scan of `m` queries over `rows` rows leaves to other streams (0: none, or another kernel)
 int pool_mq_free_cus(const cslam_pool_t* p, int m, int64_t rows) {
     if (!p || rows <= 0 || m <= 16 || m > 16 * mq_max_tiles() || p->dp % 64 != 0) return 0;
-    const MqPlan g = mq_plan(p, m, rows);
+    const MqPlan g = mq_plan(p, m, rows, 1);   // as the shard's match() will plan it
     return g.tail_strips == 0 && g.n_main > 0 ? p->cus - g.n_blocks : 0;
 }
 int64_t pool_staged_floats(const cslam_pool_t* p, int m) {
