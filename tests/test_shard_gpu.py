@@ -292,6 +292,60 @@ def test_pipelined_keyframe_table_growth(gpu):
     sh.close(); cd.close(); pool.close()
 
 
+@pytest.mark.parametrize("R,b,n,dim", [(8, 10, 20000, 128),    # five query tiles, 1250 strips: 157 blocks, staged at publish time
+                                       (3, 10, 25000, 256),    # two tiles, packed because the shard calls
+                                       (8, 10, 9000, 128)])    # fewer strips than waves: no CUs to spare, staged by the scan
+def test_sharded_step_on_a_mid_size_pool_matches_the_oracle(gpu, R, b, n, dim):
+    """The cfg4 step on a pool of tens of thousands of rows: k_scan_mq runs on just enough blocks for the
+    same strips per wave and the gathered block is staged for it at publish time, on the exchange stream
+    (csrc/shard.hip).  Robot 0 of R over the loopback communicator (every slot of the
+    gathered block holds a copy of the own block); every foreign slot's record must carry the oracle's best
+    OLD row of its descriptor - keyframe id and similarity bits - for three pipelined steps."""
+    torch = pytest.importorskip("torch")
+    from cslam_amd.multi_robot import DeviceShard, LoopbackComm
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    from oracle import knn as oracle_knn
+    me, steps = 0, 3
+    rs = np.random.RandomState(R + n)
+    base = rs.rand(n, dim).astype(np.float32)
+    pool = NearestNeighborsMatching(dim=dim, capacity_hint=n + steps * b)
+    pool.add_items(base, [700000 + i for i in range(n)])
+    cd = LoopbackComm(me, R, 0)
+    sh = DeviceShard(pool, me, R, b, 0.0, cd, cd, nb_best_matches=0)
+    blocks = []
+    for t in range(steps):
+        x = rs.rand(b, dim).astype(np.float32)
+        x[1] = base[rs.randint(n)]                    # an exact revisit of an old row
+        blocks.append((x, [1000 * (t + 1) + i for i in range(b)]))
+    dev = [torch.from_numpy(x).cuda() for x, _ in blocks]
+    got = []
+    sh.publish(dev[0], blocks[0][1])
+    for t in range(steps):
+        if t + 1 < steps:
+            sh.publish(dev[t + 1], blocks[t + 1][1])
+        sh.match()
+        got.append(sh.fetch_records())
+    rows_so_far = base
+    kf_of_row = [700000 + i for i in range(n)]
+    for t in range(steps):
+        x, kfs = blocks[t]
+        o_idx, o_sim, _ = oracle_knn.search(rows_so_far, x, 1)      # best OLD row: the rows before this step's block
+        recs = got[t]
+        for s_owner in range(1, R):                                     # the foreign slots (copies of the own block)
+            # (a descriptor may carry a second record: its best row of THIS step's block - not the one checked here)
+            mine = {int(r["robot1_keyframe_id"]): r for r in recs
+                    if int(r["robot0_id"]) == me and int(r["robot1_id"]) == s_owner and int(r["robot0_keyframe_id"]) not in kfs}
+            assert len(mine) == b, (t, s_owner, len(mine))
+            for i in range(b):
+                r = mine[kfs[i]]
+                assert int(r["robot0_keyframe_id"]) == kf_of_row[int(o_idx[i, 0])], (t, s_owner, i)
+                assert np.float32(r["weight"]).tobytes() == np.float32(o_sim[i, 0]).tobytes(), (t, s_owner, i)
+        rows_so_far = np.vstack([rows_so_far, x])
+        kf_of_row += kfs
+    assert pool.n == n + steps * b
+    sh.close(); cd.close(); pool.close()
+
+
 def test_device_shard_single_robot_and_pipelining(gpu):
     """One robot, no communicator: nothing to match against, blocks are appended; up to four steps
     may be in flight, a fifth publish without a fetch is refused loudly."""
