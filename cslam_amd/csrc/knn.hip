@@ -1516,18 +1516,43 @@ __global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restr
     const int total = w_pre[nwin];
     const uint64_t tk = tk_s;
     const float rq = rnq[q];
-    auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
-        int j = 0;
+    // window-relative row of candidate number idx: the winners hold wq or wq + 1 rows each, so winner
+    // idx / (wq + 1) is at most a step or two short
+    auto row_at = [&](int idx) -> int64_t {
+        int j = (int)(idx / (wq + 1));
+        j = j < nwin - 1 ? j : nwin - 1;
         while (j + 1 < nwin && idx >= w_pre[j + 1]) ++j;
-        const int64_t row = w_lo[j] + (idx - w_pre[j]);
+        return w_lo[j] + (idx - w_pre[j]);
+    };
+    auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
+        const int64_t row = row_at(idx);
         return make_comp((dots[q * dots_stride + row] * rnx[row]) * rq, row0 + (uint32_t)row);
     };
     // ---- B1: the rows of those waves at or above Tk --------------------------------------------
-    for (int idx = tid; idx < total; idx += 256) {
-        const uint64_t c = comp_at(idx);
-        if (c >= tk) {
-            const int pos = atomicAdd(&cnt2, 1);
-            if (pos < kTopkWavesMax) lst[pos] = c;
+    // (up to eight candidates per thread with all their loads in flight together: one memory round
+    // trip instead of one per candidate)
+    constexpr int kBatch = 8;
+    for (int base = 0; base < total; base += kBatch * 256) {
+        int64_t row[kBatch];
+        float dv[kBatch], rx[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int idx = base + e * 256 + tid;
+            row[e] = idx < total ? row_at(idx) : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const int64_t r_ = row[e] >= 0 ? row[e] : 0;
+            dv[e] = dots[q * dots_stride + r_];
+            rx[e] = rnx[r_];
+        }
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const uint64_t c = row[e] >= 0 ? make_comp((dv[e] * rx[e]) * rq, row0 + (uint32_t)row[e]) : 0;
+            if (row[e] >= 0 && c >= tk) {
+                const int pos = atomicAdd(&cnt2, 1);
+                if (pos < kTopkWavesMax) lst[pos] = c;
+            }
         }
     }
     __syncthreads();
