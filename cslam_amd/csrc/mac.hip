@@ -2199,6 +2199,41 @@ __global__ __launch_bounds__(1024) void k_topk_finish(TopkState* __restrict__ st
         if ((long long)i < krem) mask[si[i]] = 1.0;
 }
 
+// Diagnostics (cslam_mac_fw_trace_enable): the direction s_i of this iteration — the indices of
+// the k entries round_solution picked (mac.py:215), ascending — into strace[it][0..k).  One block,
+// chunked block scan over the 0/1 mask; runs in front of k_fw_dual_final, so fw_it is still i.
+__global__ __launch_bounds__(1024) void k_fw_record_s(const double* __restrict__ s, int64_t m,
+                                                      int64_t k, int32_t* __restrict__ strace,
+                                                      int cap, const Scalars* sc) {
+    if (sc->fw_done || sc->err) return;
+    const int it = sc->fw_it;
+    if (it >= cap) return;
+    int32_t* out = strace + (int64_t)it * k;
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < m; c0 += 1024) {
+        const int64_t i = c0 + threadIdx.x;
+        const int on = (i < m && s[i] != 0.0) ? 1 : 0;
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (on && off + before < k) out[off + before] = (int32_t)i;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+}
+
 // u = min(u, f + g.(s - w)); gap test (mac.py:219-225)
 // duality gap g . (s - w) in two deterministic stages: per-block partials, then one block
 __global__ __launch_bounds__(256) void k_fw_dual_part(const double* __restrict__ g,
@@ -2227,7 +2262,11 @@ __global__ __launch_bounds__(256) void k_fw_dual_final(const double* __restrict_
     const int it = sc->fw_it;
     sc->fw_f = f;
     sc->fw_u = u;
-    if (trace && it < trace_cap) trace[it] = f;
+    if (trace && it < trace_cap) {
+        trace[it] = f;
+        trace[trace_cap + it] = u;                       // dual bound after this iteration
+        trace[2 * trace_cap + it] = (double)sc->iters;   // solver iterations of its Fiedler solve
+    }
     sc->fw_alpha = 2.0 / ((double)it + 2.0);
     sc->fw_it = it + 1;
     sc->fw_done = (u - f < sc->fw_gap_tol) ? 1 : 0;
@@ -2279,6 +2318,11 @@ struct cslam_mac {
     double* trace_d = nullptr;       // lambda_2 per Frank-Wolfe iteration (asynchronous loop)
     void* arena = nullptr;           // ONE device allocation behind every buffer of mac_create
     int trace_cap = 0;
+    bool fw_trace_on = false;        // cslam_mac_fw_trace_enable: also record every direction s_i
+    int32_t* strace_d = nullptr;     // [strace_cap][strace_k] indices of s_i, ascending
+    int strace_cap = 0;
+    int64_t strace_k = 0;
+    int fw_trace_iters = 0;          // iterations the last fw_subset call recorded
     double* dual_part = nullptr;     // per-block partials of the duality-gap dot product
     long long* prof = nullptr;
     int persist_elems = 0;    // nodes per thread of the persistent solver (0 = graph path)
@@ -2862,6 +2906,7 @@ int cslam_mac_destroy(cslam_mac_t* mac) {
     if (mac->graph) (void)hipGraphExecDestroy(mac->graph);
     if (mac->arena) (void)hipFree(mac->arena);       // every buffer of mac_create lives in it
     if (mac->trace_d) (void)hipFree(mac->trace_d);   // sized by the first fw_subset call
+    if (mac->strace_d) (void)hipFree(mac->strace_d);
     if (mac->ev0) (void)hipEventDestroy(mac->ev0);
     if (mac->ev1) (void)hipEventDestroy(mac->ev1);
     if (mac->stream) (void)hipStreamDestroy(mac->stream);
@@ -3062,9 +3107,20 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
         if (mac->trace_d) (void)hipFree(mac->trace_d);
         mac->trace_d = nullptr;
         mac->trace_cap = 0;
-        CSLAM_TRY(dev_alloc(&mac->trace_d, (size_t)max_iters));
+        CSLAM_TRY(dev_alloc(&mac->trace_d, (size_t)max_iters * 3));  // f, u, solver iterations
         mac->trace_cap = max_iters;
     }
+    mac->fw_trace_iters = 0;
+    if (mac->fw_trace_on && (max_iters > mac->strace_cap || k > mac->strace_k)) {
+        if (mac->strace_d) (void)hipFree(mac->strace_d);
+        mac->strace_d = nullptr;
+        mac->strace_cap = 0;
+        mac->strace_k = 0;
+        CSLAM_TRY(dev_alloc(&mac->strace_d, (size_t)max_iters * (size_t)std::max<int64_t>(k, 1)));
+        mac->strace_cap = max_iters;
+        mac->strace_k = k;
+    }
+    const bool record_s = mac->fw_trace_on && k > 0 && k <= m;
     Scalars h;
     std::memset(&h, 0, sizeof(h));
     h.fw_u = INFINITY;
@@ -3079,6 +3135,9 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
                            mac->x, m, mac->gvec);
         launch_topk(mac->gvec, m, k, mac->svec, mac->tk_state, mac->tk_hist, mac->tk_lkey,
                     mac->tk_lidx, st);
+        if (record_s)
+            hipLaunchKernelGGL(k_fw_record_s, dim3(1), dim3(1024), 0, st, mac->svec, m, mac->strace_k,
+                               mac->strace_d, mac->strace_cap, mac->sc);
         hipLaunchKernelGGL(k_fw_dual_part, dim3(gm), dim3(256), 0, st, mac->gvec, mac->svec,
                            mac->wvec, m, mac->dual_part);
         hipLaunchKernelGGL(k_fw_dual_final, dim3(1), dim3(256), 0, st, mac->dual_part, (int)gm,
@@ -3169,9 +3228,39 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
     float ms = 0.f;
     CSLAM_HIP_TRY(hipEventElapsedTime(&ms, mac->ev0, mac->ev1));
     mac->device_ms = ms;
+    mac->fw_trace_iters = it_done;
     *upper = h.fw_u;
     if (iters_done) *iters_done = it_done;
     return cslam_mac_round_tiebreak(mac, w_relaxed, k, 10, w_round);
+}
+
+int cslam_mac_fw_trace_enable(cslam_mac_t* mac, int on) {
+    if (!mac) return fail(CSLAM_E_INVALID, "mac_fw_trace_enable: bad args");
+    mac->fw_trace_on = on != 0;
+    return CSLAM_OK;
+}
+
+int cslam_mac_fw_trace_read(cslam_mac_t* mac, int32_t it, int32_t* s_idx, int64_t* n_idx,
+                            double* f, double* u, int32_t* solver_iters) {
+    if (!mac || it < 0) return fail(CSLAM_E_INVALID, "mac_fw_trace_read: bad args");
+    if (it >= mac->fw_trace_iters || it >= mac->trace_cap)
+        return fail(CSLAM_E_INVALID, "mac_fw_trace_read: iteration %d was not evaluated (last call: %d)",
+                    (int)it, mac->fw_trace_iters);
+    CSLAM_HIP_TRY(hipSetDevice(mac->device));
+    double h[3];
+    for (int q = 0; q < 3; ++q)
+        CSLAM_HIP_TRY(hipMemcpyAsync(&h[q], mac->trace_d + (size_t)q * mac->trace_cap + it, sizeof(double),
+                                     hipMemcpyDeviceToHost, mac->stream));
+    const bool have_s = mac->fw_trace_on && mac->strace_d && it < mac->strace_cap;
+    if (s_idx && have_s)
+        CSLAM_HIP_TRY(hipMemcpyAsync(s_idx, mac->strace_d + (size_t)it * mac->strace_k,
+                                     sizeof(int32_t) * mac->strace_k, hipMemcpyDeviceToHost, mac->stream));
+    CSLAM_HIP_TRY(hipStreamSynchronize(mac->stream));
+    if (n_idx) *n_idx = have_s ? mac->strace_k : 0;
+    if (f) *f = h[0];
+    if (u) *u = h[1];
+    if (solver_iters) *solver_iters = (int32_t)h[2];
+    return CSLAM_OK;
 }
 
 int cslam_mac_stats(const cslam_mac_t* mac, int64_t* spmv_count, double* device_ms) {

@@ -72,6 +72,10 @@ class MAC:
             len(self.weights), int(device_id), ctypes.byref(self._handle)))
         self._L_odom = None
         self.last_iters = 0
+        self.trace_directions = False   # set True: fw_subset also records every direction s_i
+        self.direction_trace = []
+        self.upper_trace = np.zeros(0)
+        self.solver_iters_trace = np.zeros(0, np.int32)
 
     # ---- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -213,12 +217,14 @@ class MAC:
         upper = ctypes.c_double()
         its = ctypes.c_int32()
         self.lambda_trace = np.full(max(int(max_iters), 1), np.nan)
+        _lib.check(self._lib.cslam_mac_fw_trace_enable(self._handle, int(bool(self.trace_directions))))
         _lib.check(self._lib.cslam_mac_fw_subset(
             self._handle, _lib.ptr(w_init), int(k), int(max_iters), float(duality_gap_tol),
             _lib.ptr(w_round), _lib.ptr(w_relaxed), ctypes.byref(upper), ctypes.byref(its),
             _lib.ptr(self.lambda_trace)))
         self.fw_iters = its.value
         self.lambda_trace = self.lambda_trace[:its.value]
+        self._read_fw_trace(its.value, int(k))
         if its.value < max_iters or (its.value > 0 and max_iters > 0 and
                                      upper.value - self.lambda_trace[-1] < duality_gap_tol):
             print("Duality gap tolerance reached, found optimal solution")  # mac.py:224
@@ -227,6 +233,27 @@ class MAC:
         if 0 < k < m:   # the library already rounded w_relaxed; only a boundary tie needs numpy
             w_round = self._resolve_boundary_tie(w_relaxed, w_round, k)
         return w_round, w_relaxed, upper.value
+
+    def _read_fw_trace(self, iters, k):
+        """Per-iteration diagnostics of the last fw_subset call: dual bounds u_i (mac.py:219),
+        solver iteration counts and — with `trace_directions` — the directions s_i (mac.py:215) as
+        ascending index arrays."""
+        self.upper_trace = np.empty(iters)
+        self.solver_iters_trace = np.empty(iters, np.int32)
+        self.direction_trace = []
+        u = ctypes.c_double()
+        f = ctypes.c_double()
+        si = ctypes.c_int32()
+        n_idx = ctypes.c_int64()
+        for it in range(iters):
+            idx = np.empty(max(k, 1), np.int32) if self.trace_directions else None
+            _lib.check(self._lib.cslam_mac_fw_trace_read(
+                self._handle, it, _lib.ptr(idx) if idx is not None else None, ctypes.byref(n_idx),
+                ctypes.byref(f), ctypes.byref(u), ctypes.byref(si)))
+            self.upper_trace[it] = u.value
+            self.solver_iters_trace[it] = si.value
+            if idx is not None:
+                self.direction_trace.append(idx[:n_idx.value].copy())
 
     def stats(self):
         """(solver iterations so far, device ms of the last fiedler / fw_subset call)."""

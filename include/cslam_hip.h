@@ -269,6 +269,16 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
                         double duality_gap_tol, double* w_round, double* w_relaxed,
                         double* upper, int32_t* iters_done, double* lambda_trace);
 
+/* Diagnostics of fw_subset (mac.py:205-230), for parity tests and bench.py: with tracing enabled
+ * every later cslam_mac_fw_subset call records, per evaluated iteration i, the direction s_i
+ * (mac.py:215: the k indices round_solution picked from the gradient, ascending).  f_i (mac.py:211),
+ * the dual bound u_i (mac.py:219) and the Fiedler solver's iteration count are always recorded.
+ *   trace_read: it = iteration of the LAST fw_subset call; s_idx[k] may be NULL; *n_idx = k when
+ *   directions were recorded, else 0. */
+int cslam_mac_fw_trace_enable(cslam_mac_t* mac, int on);
+int cslam_mac_fw_trace_read(cslam_mac_t* mac, int32_t it, int32_t* s_idx, int64_t* n_idx,
+                            double* f, double* u, int32_t* solver_iters);
+
 /* Solver statistics of the last cslam_mac_fiedler / cslam_mac_fw_subset call. */
 int cslam_mac_stats(const cslam_mac_t* mac, int64_t* spmv_count, double* device_ms);
 

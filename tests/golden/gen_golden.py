@@ -243,6 +243,81 @@ def gen_mac():
 
 
 # ----------------------------------------------------------------------------------------------
+# MAC at BASELINE configs[2] size: the reference's Frank-Wolfe trajectory on the cfg3 graph
+# ----------------------------------------------------------------------------------------------
+CFG3_TEACHER_ITERATES = (0, 1, 2, 5, 8, 13, 16, 19)
+CFG3_TOP = 1200          # gradient entries kept around the top-k boundary (k = 500)
+
+
+def _sparse(w):
+    idx = np.nonzero(w)[0].astype(np.int32)
+    return idx, np.asarray(w)[idx].astype(np.float64)
+
+
+def gen_mac_cfg3():
+    """`MAC.fw_subset` (mac.py:191-233) of the REFERENCE on the cfg3 graph (2 x 25 000 poses,
+    200 000 candidates, budget 500, 20 iterations, greedy w_init), twice:
+      * "ref":   as shipped — networkx TraceMIN-LU stopped at its default tol = 1e-8 (mac.py:35);
+      * "tight": the same code with `evaluate_fiedler_pair(w, tol=1e-12)` (the reference's own
+                 keyword, mac.py:79): its converged-solver trajectory.
+    Kept per run: f_i, u_i, the direction s_i of every iteration, the rounded selection and its
+    lambda_2; for "ref" also the iterates w_i (sparse) and the top of the gradient at
+    CFG3_TEACHER_ITERATES — what a teacher-forced parity test needs.  ~3 min on one core."""
+    sys.path.insert(0, ROOT)
+    from tools.mac_bench_util import cfg3_graph, greedy_w
+    n, fixed, cand = cfg3_graph()
+    k = 500
+    w0 = greedy_w(cand, k)
+    out = {"nb": np.array([n, len(fixed), len(cand), k, 20], np.int64),
+           "graph_checksum": np.array([sum(e.i for e in cand), sum(e.j for e in cand)], np.int64),
+           "graph_weight_sum": np.float64(sum(e.weight for e in cand)),
+           "teacher_iterates": np.array(CFG3_TEACHER_ITERATES, np.int32)}
+    wi, wv = _sparse(w0)
+    out["w_init_idx"] = wi
+    for tag, tol in (("ref", None), ("tight", 1e-12)):
+        mac = MAC(fixed, cand, n)
+        trace = []
+        orig = mac.evaluate_fiedler_pair
+
+        def spy(w, method="tracemin_lu", tol_=1e-8, _orig=orig, _trace=trace, _tol=tol):
+            f, v = _orig(w, method, tol_ if _tol is None else _tol)
+            _trace.append((np.array(w, dtype=np.float64), float(f), np.array(v)))
+            return f, v
+
+        mac.evaluate_fiedler_pair = spy
+        with contextlib.redirect_stdout(io.StringIO()):
+            rounded, relaxed, upper = mac.fw_subset(w0, k, max_iters=20)
+        assert len(trace) == 20
+        u = float("inf")
+        s_all, u_all = [], []
+        for it, (w, f, v) in enumerate(trace):
+            g = mac.grad_from_fiedler(v)
+            s = mac.round_solution(g, k)
+            u = min(u, f + g @ (s - w))
+            s_all.append(np.nonzero(s)[0].astype(np.int32))
+            u_all.append(u)
+            if tag == "ref" and it in CFG3_TEACHER_ITERATES:
+                out[f"ref_w{it}_idx"], out[f"ref_w{it}_val"] = _sparse(w)
+                top = np.argsort(-g, kind="stable")[:CFG3_TOP].astype(np.int32)
+                out[f"ref_g{it}_idx"] = top
+                out[f"ref_g{it}_val"] = g[top]
+        assert u == upper
+        mac.evaluate_fiedler_pair = orig
+        lam_sel = mac.evaluate_objective(rounded)   # lambda_2 of the rounded selection (default tol)
+        out[f"{tag}_f"] = np.array([t[1] for t in trace])
+        out[f"{tag}_u"] = np.array(u_all)
+        out[f"{tag}_s"] = np.stack(s_all)
+        out[f"{tag}_rounded_idx"] = np.nonzero(rounded)[0].astype(np.int32)
+        out[f"{tag}_relaxed_idx"], out[f"{tag}_relaxed_val"] = _sparse(relaxed)
+        out[f"{tag}_upper"] = np.float64(upper)
+        out[f"{tag}_lambda2_of_selection"] = np.float64(lam_sel)
+        print("mac_cfg3", tag, "f first/last", trace[0][1], trace[-1][1], "lambda2(selection)", lam_sel)
+    ov = len(set(out["ref_rounded_idx"]) & set(out["tight_rounded_idx"]))
+    print("mac_cfg3: |sel(ref) & sel(tight)| =", ov, "of", k)
+    np.savez_compressed(os.path.join(OUT, "mac_cfg3_ref.npz"), **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # AlgebraicConnectivityMaximization bookkeeping traces (quirks of SURVEY.md Appendix A)
 # ----------------------------------------------------------------------------------------------
 def _edge_list(edges):
@@ -724,6 +799,8 @@ if __name__ == "__main__":
     gen_misc()
     gen_knn()
     gen_mac()
+    if "--skip-cfg3" not in sys.argv:
+        gen_mac_cfg3()
     gen_acm()
     gen_lcsm()
     gen_broker()

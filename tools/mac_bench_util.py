@@ -73,6 +73,48 @@ def fiedler_bench(budget=500, reps=5):
     out["fw_subset_device_ms"] = mac.stats()[1]
     out["fw_subset_solver_iters"] = mac.stats()[0]
     out["fw_lambda2_first_last"] = [float(mac.lambda_trace[0]), float(mac.lambda_trace[-1])]
+    out["fw_lambda_trace"] = [float(x) for x in mac.lambda_trace]
+    mac.close()
+    if budget == 500:
+        out["fw_selection_parity"] = fw_selection_parity(n, fixed, cand, w0, budget)
+    return out
+
+
+def fw_selection_parity(n, fixed, cand, w0, budget):
+    """The HIP Frank-Wolfe loop beside the REFERENCE's own runs on the same graph and w_init
+    (tests/golden/mac_cfg3_ref.npz: cslam/mac/mac.py:191-233 at its default solver tol 1e-8 and at
+    tol 1e-12; recorded in the build container, no CPU time spent here): both lambda traces, the
+    first iteration whose direction s_i differs, the overlap of the rounded selections and lambda_2
+    of each selection (all three evaluated by the HIP solver).  Untimed (directions recorded)."""
+    import os
+    fx = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                      "mac_cfg3_ref.npz")
+    if not os.path.exists(fx):
+        return {"error": "tests/golden/mac_cfg3_ref.npz missing"}
+    ref = np.load(fx)
+    if [sum(e.i for e in cand), sum(e.j for e in cand)] != ref["graph_checksum"].tolist():
+        return {"error": "fixture is for another graph"}
+    mac = MAC(fixed, cand, n)
+    mac.trace_directions = True
+    with redirect_stdout(io.StringIO()):
+        rounded, relaxed, upper = mac.fw_subset(w0, budget, max_iters=20)
+    sel = set(np.nonzero(rounded)[0].tolist())
+    out = {"hip_lambda_trace": [float(x) for x in mac.lambda_trace],
+           "hip_lambda2_of_selection": float(mac.evaluate_objective(rounded)),
+           "contract": "DESIGN.md §3b: identical to the reference with a converged eigen-solver; the "
+                       "default-tolerance reference differs from its own converged self by as much"}
+    for tag, name in (("ref", "reference_default_tol_1e-8"), ("tight", "reference_tol_1e-12")):
+        s = ref[f"{tag}_s"]
+        ov = [len(set(mac.direction_trace[i].tolist()) & set(s[i].tolist())) for i in range(len(s))]
+        w = np.zeros(len(cand))
+        w[ref[f"{tag}_rounded_idx"]] = 1.0
+        out[name] = {"lambda_trace": [float(x) for x in ref[f"{tag}_f"]],
+                     "first_differing_direction": next((i for i, o in enumerate(ov) if o != budget), None),
+                     "direction_overlap_min": int(min(ov)),
+                     "selection_overlap": len(sel & set(ref[f"{tag}_rounded_idx"].tolist())),
+                     "lambda2_of_selection": float(mac.evaluate_objective(w))}
+    out["reference_default_vs_reference_converged_selection_overlap"] = len(
+        set(ref["ref_rounded_idx"].tolist()) & set(ref["tight_rounded_idx"].tolist()))
     mac.close()
     return out
 
