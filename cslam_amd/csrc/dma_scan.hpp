@@ -9,9 +9,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace cslam {
 
+// COVERS = true: the caller's count says that every INLINE-ASM load issued so far has landed when
+// the wait returns (k_scan_dma's query fragments; tie_b() follows).  The region is bracketed by
+// assembly comments that tools/check_asm_load_hazard.py reads: it cannot follow a run-time count,
+// so it takes the kernel's word at a COVERS selector (the bit-exact tests check that word) and
+// keeps every asm load owed across the others.
+template <bool COVERS = false>
 __device__ inline void wait_vm_dyn(int n) {
     // s_waitcnt takes an immediate: wave-uniform switch over the exact count (vmcnt is 6 bits;
     // more than 48 younger operations cannot hide anything that is still needed here)
+    asm volatile("; cslam.wait_dyn.begin" ::: "memory");
 #define CSLAM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (n) {
         CSLAM_W(0) CSLAM_W(1) CSLAM_W(2) CSLAM_W(3) CSLAM_W(4) CSLAM_W(5) CSLAM_W(6) CSLAM_W(7)
@@ -24,8 +31,11 @@ __device__ inline void wait_vm_dyn(int n) {
         default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
     }
 #undef CSLAM_W
+    if (COVERS)
+        asm volatile("; cslam.wait_dyn.end covers-asm-loads" ::: "memory");
+    else
+        asm volatile("; cslam.wait_dyn.end" ::: "memory");
 }
-
 
 // Slice width KW (floats): 256 = one row per DMA instruction.  KW = 128 / 64: one DMA instruction
 // moves R = 256 / KW ROWS x KW floats (lanes [k 64/R, (k+1) 64/R) fetch row k of the piece).  The

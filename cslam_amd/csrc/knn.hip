@@ -353,7 +353,8 @@ constexpr int kDmaStageB = 16 * kDmaPieceB;    // 16 rows x 256 floats
 constexpr int64_t kDmaMinRows = 1;
 
 // NB B fragments (one KW-float slice of the lane's query column, NB = KW / 16) by inline-asm
-// loads; the registers may only be read behind a counted wait followed by tie_b()
+// loads; the registers may only be read behind a counted wait followed by tie_b().  What the compiler
+// does with them in between is checked on the emitted assembly at every build (Makefile: asm-check)
 template <int NB>
 __device__ inline void load_b(f32x4 (&b)[NB], const float* qrow) {
 #define CSLAM_LB(I)                                                                     \
@@ -363,14 +364,22 @@ __device__ inline void load_b(f32x4 (&b)[NB], const float* qrow) {
     CSLAM_LB(8) CSLAM_LB(9) CSLAM_LB(10) CSLAM_LB(11) CSLAM_LB(12) CSLAM_LB(13) CSLAM_LB(14) CSLAM_LB(15)
 #undef CSLAM_LB
 }
+// behind the counted wait that covers the loads: tells the compiler the registers changed
 template <int NB>
 __device__ inline void tie_b(f32x4 (&b)[NB]) {
 #pragma unroll
     for (int i = 0; i < NB; i += 4)
         asm volatile("" : "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), "+v"(b[i + 3]));
 }
+// prologue: everything in flight has landed; wait and tie of the first fragments in ONE statement
+template <int NB>
+__device__ inline void wait0_tie_b(f32x4 (&b)[NB]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
+#pragma unroll
+    for (int i = 4; i < NB; i += 4)
+        asm volatile("" : "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), "+v"(b[i + 3]));
+}
 __device__ inline void load_b16(f32x4 (&b)[16], const float* qrow) { load_b<16>(b, qrow); }
-__device__ inline void tie16(f32x4 (&b)[16]) { tie_b<16>(b); }
 
 struct DmaCursor {   // position of a stage in a wave's work list
     int64_t lo;      // first row of the panel
@@ -439,6 +448,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     // many of its waves ask: 625 strips as 157 full blocks ran at 3.5 TB/s)
     const int w = (even & 2) ? wave * (int)gridDim.x + (int)blockIdx.x : blockIdx.x * NW + wave;
     char* ring = dma_lds + wave * NST * kStage;
+    // BEST: 1/||x|| of the wave's panel rows (<= 128 floats), fetched by LDS-DMA - a load without a
+    // VGPR destination leaves nothing the compiler could copy or recycle while it is in flight
+    char* rvbuf = dma_lds + NW * NST * kStage + wave * 512;
     const int nkc = dp / KW;
     if (w >= n_waves) return;
     // wave w owns the rows [wlo, whi) of an even split of the window over the waves and walks
@@ -508,7 +520,6 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     f32x4 bc[NB], bn[NB];
     float ss[16];  // BEST: sum-of-squares chains of norm lanes 4i + g of query r
     float rnq = 0.f;
-    float rv0 = 0.f, rv1 = 0.f;  // BEST: 1/||x|| of the panel's rows, one row per lane and register
 #pragma unroll
     for (int i = 0; i < 16; ++i) ss[i] = 0.f;
     DmaCursor ic;  // issue cursor: runs NST stages ahead of the consumer
@@ -523,8 +534,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         yq += k;
     };
     load_b<NB>(bn, qrow);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tie_b<NB>(bn);
+    wait0_tie_b<NB>(bn);
 #if defined(CSLAM_DMA_PROBE_CLOCK)
     pc_r1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -563,16 +573,22 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NB; ++i) bc[i] = bn[i];
             if (BEST) {
-                // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l fetches rows lo + l
-                // and lo + 64 + l (clamped into the window).  Issued IN FRONT of the B loads, so
-                // the counted wait for those at the end of the slice covers these two as well.
+                // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l moves the norms of rows
+                // lo + l and lo + 64 + l (clamped into the window) into the wave's LDS area (two 256-B
+                // LDS-DMA pieces).  Issued IN FRONT of the B loads, so the counted wait for those at
+                // the end of the slice covers these two as well; the epilogue reads them back with
+                // one ds_read_b128 per row group.
                 // (Ordinary loads in the epilogue made hipcc wait vmcnt(0) 32 times per panel:
-                // 32 dependent memory round trips with the ring drained.)
+                // 32 dependent memory round trips with the ring drained.  Rounds 2-3 used inline-asm
+                // loads into two VGPRs here: registers the compiler may not touch while the load is
+                // in flight but does not know about - ADVICE r03.)
                 int64_t i0 = lo + lane, i1 = lo + 64 + lane;
                 i0 = i0 < n ? i0 : n - 1;
                 i1 = i1 < n ? i1 : n - 1;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(rv0) : "v"(rnx + i0) : "memory");
-                asm volatile("global_load_dword %0, %1, off" : "=v"(rv1) : "v"(rnx + i1) : "memory");
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rnx + i0),
+                                                 (__attribute__((address_space(3))) void*)rvbuf, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rnx + i1),
+                                                 (__attribute__((address_space(3))) void*)(rvbuf + 256), 4, 0, 0);
                 bump(2);
             }
             load_b<NB>(bn, qrow + (kc + 1 < nkc ? kc + 1 : 0) * KW);
@@ -637,9 +653,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
                     slot = slot + 1 == NST ? 0 : slot + 1;
                 }
             }
-            wait_vm_dyn(yq);
+            wait_vm_dyn<true>(yq);   // the B loads (and the row norms in front of them) have landed
             tie_b<NB>(bn);
-            if (BEST) asm volatile("" : "+v"(rv0), "+v"(rv1));
         }
         if (norms && p == p_begin) {
             // butterfly 32, 16, 8, 4 of the norm lanes = register index xor 8, 4, 2, 1;
@@ -673,10 +688,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (s < ns) {
-                        float rn[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
+                        const f32x4 rn = *reinterpret_cast<const f32x4*>(rvbuf + (16 * s + 4 * g) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int rel = 16 * s + 4 * g + e;
@@ -691,10 +703,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (s < ns) {
-                        float rn[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, kWave);
+                        const f32x4 rn = *reinterpret_cast<const f32x4*>(rvbuf + (16 * s + 4 * g) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int rel = 16 * s + 4 * g + e;
@@ -830,8 +839,7 @@ __global__ __launch_bounds__(256) void k_scan_dma_ks(const float* __restrict__ X
         const int kc_first = cc.kc;
         f32x4 bc[16], bn[16];
         load_b16(bn, qrow + cc.kc * 256);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tie16(bn);
+        wait0_tie_b<16>(bn);
         int y_next = 0;   // pieces of the stage behind the consumer's (0: none in flight)
         issue(ci, ring);
         advance(ci);
@@ -873,8 +881,8 @@ __global__ __launch_bounds__(256) void k_scan_dma_ks(const float* __restrict__ X
                 part[(cc.s * nchunks + (cc.kc >> 1)) * 64 + lane] = acc;
                 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            wait_vm_dyn(y_refill);   // the B loads have landed (only the refill is younger)
-            tie16(bn);
+            wait_vm_dyn<true>(y_refill);   // the B loads have landed (only the refill is younger)
+            tie_b<16>(bn);
             slot ^= 1;
             y_next = y_refill;
             cc = cn;
@@ -1861,7 +1869,7 @@ int launch_scan_dma(cslam_pool* p, const float* Q, int64_t q_stride, int q_rows,
     const bool nt = (size_t)p->vn * p->xs * sizeof(float) > ((size_t)192 << 20);
 #define CSLAM_DMA_LAUNCH(AUX, BEST, KW, DT)                                                         \
     do {                                                                                          \
-        const size_t lds = (size_t)NW * NST * DmaGeom<KW>::kStage;                                \
+        const size_t lds = (size_t)NW * NST * DmaGeom<KW>::kStage + (size_t)NW * 512; /* + row norms */ \
         static bool attr_set[64] = {};  /* per device: the attribute is per device code object */ \
         if (!attr_set[p->device & 63]) {                                                          \
             CSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_scan_dma<NS, NW, NST, AUX, BEST, KW, DT>, \
@@ -2044,32 +2052,69 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
     // pool then goes the tail's way when the K split pays
     if (knob(k_tail) && tail > 0) {
         // cost in strip times (one strip through all slices): q + 1 as one launch; with the tail
-        // K-split over ks parts: q + 1/ks + the extra launches (~5 us of ~10 us per chunk)
-        // A large tail (25 000 rows: 539 of 1563 strips) takes several rounds of K-split blocks -
-        // each a chunk or two of work behind ~4 us of start-up latency - and still beats a second
-        // strip for every wave: 1 + 5 rounds x (1/8 + 0.05) against 2 strip times.
-        const int64_t groups = (tail + g.waves - 1) / g.waves;
-        static Knob k_rounds{"CSLAM_MQ_TAIL_ROUNDS", 6};   // most rounds of tail blocks (1: round 3's first rule)
-        int64_t ks = 1;
+        // K-split: q + (strip, chunk) units of the busiest tail wave / chunks + the extra launches.
+        // Two shapes of tail launch:
+        //  (a) ONE WAVE OF BLOCKS (round 4): groups x ks <= CUs blocks, each a group of spb strips
+        //      (ceil(spb / waves) per wave, walked in rounds inside the block: the DMA ring and the
+        //      query slices keep streaming across them) x the chunks of its K part.  25 000 rows:
+        //      539 tail strips = 32 groups x 8 parts, 5 units per wave = 0.625 strip times behind
+        //      the main launch's one strip - against a second whole strip for every wave;
+        //  (b) groups of one strip per wave, several rounds of small blocks handed out by the
+        //      dispatcher (round 3): each block a chunk or two of work behind ~4 us of start-up.
+        static Knob k_rounds{"CSLAM_MQ_TAIL_ROUNDS", 6};   // (b): most rounds of tail blocks
+        static Knob k_shape{"CSLAM_MQ_TAIL_SHAPE", 0};     // A/B: 1 = (a) only, 2 = (b) only
+        int64_t best_groups = 0, best_ks = 1;
         double part_cost = 1e9;
-        for (int64_t k = 1; k <= g.nchunks; ++k) {   // K parts per strip group: the cheapest split
-            const int64_t r = (groups * k + p->cus - 1) / p->cus;
-            const double c = r * ((double)((g.nchunks + k - 1) / k) / g.nchunks + 0.4 / g.nchunks) + 0.2 / g.nchunks;
-            if (r <= knob(k_rounds) && c < part_cost) {
-                part_cost = c;
-                ks = k;
+        const double startup = 0.4 / g.nchunks, launches = 0.2 / g.nchunks;
+        if (knob(k_shape) != 2) {
+            for (int64_t k = 1; k <= g.nchunks; ++k) {
+                int64_t groups = p->cus / k;
+                const int64_t most = (tail + g.waves - 1) / g.waves;   // a strip per wave at least
+                if (groups > most) groups = most;
+                if (groups < 1) continue;
+                const int64_t spb = (tail + groups - 1) / groups;          // strips of the largest group
+                const int64_t spw = (spb + g.waves - 1) / g.waves;         // ... of its busiest wave
+                const int64_t cpb = (g.nchunks + k - 1) / k;               // chunks of the largest K part
+                const double c = (double)(spw * cpb) / g.nchunks + startup + launches;
+                if (c < part_cost - 1e-9) {
+                    part_cost = c;
+                    best_groups = groups;
+                    best_ks = k;
+                }
             }
         }
-        // percent of a strip time the split may cost: the model is optimistic about multi-round tails -
-        // at 90 / 100 the 25 000-row pool's 80-query pass goes 207 -> 216 us, 60 000 rows 368 -> 381
-        // (profiles/r03_mq_tail_cost_ab.txt)
+        if (knob(k_shape) != 1) {
+            const int64_t groups = (tail + g.waves - 1) / g.waves;
+            for (int64_t k = 1; k <= g.nchunks; ++k) {   // K parts per strip group: the cheapest split
+                const int64_t r = (groups * k + p->cus - 1) / p->cus;
+                const double c = r * ((double)((g.nchunks + k - 1) / k) / g.nchunks + startup) + launches;
+                if (r <= knob(k_rounds) && c < part_cost - 1e-9) {
+                    part_cost = c;
+                    best_groups = groups;
+                    best_ks = k;
+                }
+            }
+        }
+        // percent of a strip time the split may cost (the model is optimistic about multi-round tails of
+        // shape (b): at 90 / 100 the 25 000-row pool's 80-query pass went 207 -> 216 us, 60 000 rows
+        // 368 -> 381, profiles/r03_mq_tail_cost_ab.txt)
         static Knob k_cost{"CSLAM_MQ_TAIL_MAXCOST", 80};
-        if (part_cost < (q >= 1 ? knob(k_cost) * 0.01 : 0.85)) {
+        if (best_groups > 0 && part_cost < (q >= 1 ? knob(k_cost) * 0.01 : 0.85)) {
             g.n_main = 16 * q * waves;
             g.tail_strips = tail;
-            g.tail_groups = (int)groups;
-            g.tail_ks = (int)ks;
+            g.tail_groups = (int)best_groups;
+            g.tail_ks = (int)best_ks;
         }
+    }
+    // A/B and measurement: the WHOLE window through the K-split launch + combine, as `groups` strip
+    // groups x `ks` K parts ("groups,ks"; no main launch)
+    static Knob k_allpart_g{"CSLAM_MQ_ALLPART_GROUPS", 0};
+    static Knob k_allpart_k{"CSLAM_MQ_ALLPART_KS", 0};
+    if (knob(k_allpart_g) > 0 && knob(k_allpart_k) > 0 && knob(k_allpart_k) <= g.nchunks) {
+        g.n_main = 0;
+        g.tail_strips = strips;
+        g.tail_groups = (int)std::min<int64_t>(knob(k_allpart_g), (strips + g.waves - 1) / g.waves);
+        g.tail_ks = knob(k_allpart_k);
     }
     const int64_t strips_main = (g.n_main + 15) / 16;
     // A wave's time is its number of whole strips: 1563 strips need two per wave on 256 CUs (6 or 7 per

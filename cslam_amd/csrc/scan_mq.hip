@@ -83,6 +83,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     const int r = lane & 15, g = lane >> 4;
     char* ring = mq_lds + wave * NST * kStage;
     char* bbuf = mq_lds + NW * NST * kStage;   // [2][T][kStage]
+    // MODE_BEST: 1/||x|| of the wave's panel rows (<= 128 floats), fetched by LDS-DMA - no VGPR
+    // destination an in-flight load could owe
+    char* rvbuf = bbuf + 2 * T * kStage + wave * 1024;   // + 1 / ||q|| of the 16 T queries behind them
     const int nkc_all = A.dp / KW;
     // MODE_PART (K-split launch): grid = n_blocks strip groups x part_ks K parts; this block multiplies
     // the whole 512-float chunks [chunk_lo, chunk_hi) of its rows only
@@ -190,37 +193,55 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     };
     // this wave's share of the B pieces of slice kc -> buffer bb: pieces wave, wave + NW, ... of the
     // slice's T NP (piece pi = tile pi / NP, piece pi % NP of the tile)
+    // B pieces: piece pi = wave + NW x of a slice holds the query rows R pi .. R pi + R - 1, so its source is
+    //   [Q + R wave dp + slice]  (uniform, a scalar pair re-made per step and opaque to the optimiser)
+    //   + x (R NW dp floats)     (uniform, 32 bits)        + this lane's row / segment (one VGPR).
+    // Written any simpler, the loop optimiser turns the T NP / NW pieces into as many loop-invariant
+    // 64-bit per-lane addresses: 20 registers alive through the whole kernel at T = 5, one of them
+    // spilled - and reloaded, with a vmcnt(0), in the middle of every step.
+    const uint32_t b_lane_off = (uint32_t)(sub * A.dp + seg * 4) * 4u;
+    const uint32_t b_stride = (uint32_t)(R * NW * A.dp) * 4u;
+    const char* const b_wave = reinterpret_cast<const char*>(A.Q + (int64_t)(R * wave) * A.dp + (int64_t)kc_begin * KW);
+    uint32_t b_lo = 0, b_hi = 0;   // scalar pair: source of this wave's piece 0 of the slice being requested
+    auto b_slice = [&](int kc) {
+        const uint64_t v = reinterpret_cast<uint64_t>(b_wave + (int64_t)kc * (KW * 4));
+        b_lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+        b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        asm volatile("" : "+s"(b_lo), "+s"(b_hi));
+    };
     auto issue_b_piece = [&](int x, int kc, int bb) {
         const int pi = wave + NW * x;
         if (pi < T * NP) {   // wave-uniform
             const int t = pi / NP, pp = pi % NP;
-            const float* a = A.Q + (int64_t)(16 * t + R * pp + sub) * A.dp + (kc_begin + kc) * KW + seg * 4;
+            const char* ub = reinterpret_cast<const char*>(((uint64_t)b_hi << 32) | b_lo) + (uint32_t)x * b_stride;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)a,
+                (const __attribute__((address_space(1))) void*)(ub + b_lane_off),
                 (__attribute__((address_space(3))) void*)(bbuf + (bb * T + t) * kStage + pp * kPiece), 16, 0, 0);
             ++issued;
         }
     };
     auto issue_b = [&](int kc, int bb) {
+        b_slice(kc);
 #pragma unroll
         for (int x = 0; x < NBPX; ++x) issue_b_piece(x, kc, bb);
         mark_b = issued;
     };
 
     // ---- prologue -----------------------------------------------------------------------------
-    // MODE_BEST: 1 / ||q|| of this lane's query column in every tile.  Inline-asm loads, waited for
-    // here: an ordinary load makes hipcc drain vmcnt(0) - the whole ring - at its first use.
-    float rq[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        rq[t] = 0.f;
-        if (MODE == MODE_BEST)
-            asm volatile("global_load_dword %0, %1, off" : "=v"(rq[t]) : "v"(A.rnq + 16 * t + r) : "memory");
-    }
+    // MODE_BEST: 1 / ||q|| of the 16 T staged queries goes to the LDS once (every wave its own copy behind
+    // its row norms: no barrier), by LDS-DMA; the epilogue reads the lane's T values back.  Held in
+    // registers they were T more live through the stage loop of a kernel that sits at the register
+    // ceiling; loaded in the epilogue they would drain the ring (hipcc waits vmcnt(0) for an ordinary load).
     if (MODE == MODE_BEST) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < T; ++t) asm volatile("" : "+v"(rq[t]));
+        const int qi = lane < 16 * T ? lane : 16 * T - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.rnq + qi),
+                                         (__attribute__((address_space(3))) void*)(rvbuf + 512), 4, 0, 0);
+        if (16 * T > 64) {
+            const int qj = 64 + lane < 16 * T ? 64 + lane : 16 * T - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.rnq + qj),
+                                             (__attribute__((address_space(3))) void*)(rvbuf + 512 + 256), 4, 0, 0);
+        }
+        issued += 16 * T > 64 ? 2 : 1;   // older than everything the waits of the stage loop count
     }
     issue_b(0, 0);
 #pragma unroll
@@ -256,7 +277,6 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                 // architectural VGPRs between a strip's stages - 8 NS T of them - and spills)
                 asm volatile("" : "+a"(acc[s][t]), "+a"(tot[s][t]));
             }
-        float rv0 = 0.f, rv1 = 0.f;   // MODE_BEST: 1/||x|| of the panel's rows, one row per lane
         for (int kc = 0; kc < nkc; ++kc, ++gstep) {
             const int bb = gstep & 1;
             // my B pieces of this slice have landed ... and so have everybody's; everybody is also
@@ -275,15 +295,23 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             pc_wait_bar += __builtin_amdgcn_s_memtime() - pc_b1;
 #endif
             if (MODE == MODE_BEST) {
-                // 1/||x|| of the panel's <= 128 rows for the epilogue, lane l rows lo + l and
-                // lo + 64 + l (clamped into the window).  Issued at EVERY step, unconditionally (an
-                // asm load inside a conditional leaves the compiler free to copy its not-yet-written
-                // output at the join); waited for and tied in front of the epilogue.
-                int64_t i0 = lo + lane, i1 = lo + 64 + lane;
-                i0 = i0 < A.n ? i0 : A.n - 1;
-                i1 = i1 < A.n ? i1 : A.n - 1;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(rv0) : "v"(A.rnx + i0) : "memory");
-                asm volatile("global_load_dword %0, %1, off" : "=v"(rv1) : "v"(A.rnx + i1) : "memory");
+                // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l moves the norms of rows
+                // lo + l and lo + 64 + l (clamped into the window) into the wave's LDS area, two 256-B
+                // LDS-DMA pieces.  Issued at EVERY step (the same values again: the waits of the stage
+                // loop stay compile-time counts); waited for in front of the epilogue, which reads
+                // them back with one ds_read_b128 per strip.
+                // (uniform base + a 32-bit lane offset: two registers live through the step loop, not two
+                // 64-bit addresses)
+                // (a wave without rows in this round has lo at or behind the window's end: clamped too)
+                const int64_t lo_c = lo < A.n ? lo : A.n - 1;
+                const int64_t last = A.n - 1 - lo_c;   // >= 0
+                const uint32_t o0 = (uint32_t)(lane < last ? lane : last) * 4u;
+                const uint32_t o1 = (uint32_t)(64 + lane < last ? 64 + lane : last) * 4u;
+                const char* rb = reinterpret_cast<const char*>(A.rnx + lo_c);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + o0),
+                                                 (__attribute__((address_space(3))) void*)rvbuf, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + o1),
+                                                 (__attribute__((address_space(3))) void*)(rvbuf + 256), 4, 0, 0);
                 issued += 2;
                 mark_rv = issued;
             }
@@ -292,6 +320,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             // DMA issues at the top of the step kept the matrix pipe idle ~600 clocks per step)
             const int kc_nx = kc + 1 == nkc ? 0 : kc + 1;
             if (ns == 0) issue_b(kc_nx, bb ^ 1);
+            else b_slice(kc_nx);
             const char* bs = bbuf + bb * T * kStage + rd_off;
             // end of a 512-float chunk / of the row: fold (or, MODE_PART, hand the partial over)
             const bool fold = (((kc_begin + kc + 1) & (kFold - 1)) == 0) || kc_begin + kc + 1 == nkc_all;
@@ -399,6 +428,13 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 #pragma unroll
                     for (int t = 0; t < T; ++t) asm volatile("" : "+a"(acc[s][t]));
                     if (__builtin_expect(fold, 0)) {
+                        // the zero the accumulators restart from, made HERE: as a loop invariant the
+                        // compiler kept one zero float4 alive through the whole kernel, spilled it, and
+                        // reloaded it in every fold - and a scratch reload is followed by vmcnt(0): the
+                        // wave's whole DMA ring drained once per strip and chunk
+                        float z;
+                        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                        const f32x4 zero4{z, z, z, z};
                         if (MODE == MODE_PART) {
                             // the partial of chunk c of this strip, in the layout k_mq_combine folds
                             const int64_t strip = (lo >> 4) + s;   // panels are strip-aligned
@@ -407,14 +443,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
                                 out[t * 64] = acc[s][t];
-                                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                acc[s][t] = zero4;
                                 asm volatile("" : "+a"(acc[s][t]));
                             }
                         } else {
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
                                 tot[s][t] = tot[s][t] + acc[s][t];
-                                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                acc[s][t] = zero4;
                                 asm volatile("" : "+a"(acc[s][t]), "+a"(tot[s][t]));
                             }
                         }
@@ -425,64 +461,62 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
         }
         // ---- panel epilogue ---------------------------------------------------------------
         if (MODE == MODE_BEST) {
-            wait_vm_dyn(issued - mark_rv);
-            asm volatile("" : "+v"(rv0), "+v"(rv1));
-            uint64_t best[T], best_c[T];
+            wait_vm_dyn(issued - mark_rv);   // the row norms of this panel sit in rvbuf
+            // This lane's position, opaque from here on: everything the epilogue derives from (r, g) alone -
+            // the 4 NS row offsets 16 s + 4 g + e, the T candidate addresses (16 t + r) cand_stride, the
+            // LDS offsets of the norms - is loop-invariant, and hoisted out of the round loop it stays
+            // live through the stage loop: ~60 registers, i.e. spills, which the allocator put INTO the
+            // stage loop (scratch reload = vmcnt(0) = the wave's DMA ring drained at every fold).
+            int er = r, eg = g;
+            asm volatile("" : "+v"(er), "+v"(eg));
+            // One query tile after the other (scheduling barriers in between): two composites, four row
+            // norms and the values of one strip are all that is live - with every tile's running best
+            // held at once the epilogue was the register peak of the kernel.
+            const int64_t hi = lo + rows;
+            const bool two = A.split < hi;   // wave-uniform: rows >= split in this panel
+            const uint32_t rbase = A.row0 + (uint32_t)lo;
+            const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
+            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * NW + wave;
 #pragma unroll
-            for (int t = 0; t < T; ++t) best[t] = best_c[t] = 0;
-            if (ns > 0) {
-                const int64_t hi = lo + rows;
-                const bool two = A.split < hi;   // wave-uniform: rows >= split in this panel
-                const uint32_t rbase = A.row0 + (uint32_t)lo;
-                const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
+            for (int t = 0; t < T; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                uint64_t best = 0, best_c = 0;
+                const float rq = *reinterpret_cast<const float*>(rvbuf + 512 + (16 * t + er) * 4);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (s < ns) {
-                        float rn[4];
+                        const f32x4 rn = *reinterpret_cast<const f32x4*>(rvbuf + (16 * s + 4 * eg) * 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            rn[e] = __shfl(s < 4 ? rv0 : rv1, 16 * (s & 3) + 4 * g + e, 64);
-#pragma unroll
-                        for (int t = 0; t < T; ++t)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int rel = 16 * s + 4 * g + e;
-                                const float sim = (tot[s][t][e] * rn[e]) * rq[t];
-                                uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
-                                c = rel < rows ? c : 0;
-                                if (two) {
-                                    const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
-                                    best[t] = ca > best[t] ? ca : best[t];
-                                    best_c[t] = cc > best_c[t] ? cc : best_c[t];
-                                } else {
-                                    best[t] = c > best[t] ? c : best[t];
-                                }
+                        for (int e = 0; e < 4; ++e) {
+                            const int rel = 16 * s + 4 * eg + e;
+                            const float sim = (tot[s][t][e] * rn[e]) * rq;
+                            uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
+                            c = rel < rows ? c : 0;
+                            if (two) {
+                                const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
+                                best = ca > best ? ca : best;
+                                best_c = cc > best_c ? cc : best_c;
+                            } else {
+                                best = c > best ? c : best;
                             }
+                        }
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    uint64_t o = __shfl_xor(best[t], 16, 64);
-                    best[t] = o > best[t] ? o : best[t];
-                    o = __shfl_xor(best[t], 32, 64);
-                    best[t] = o > best[t] ? o : best[t];
-                    if (two) {
-                        o = __shfl_xor(best_c[t], 16, 64);
-                        best_c[t] = o > best_c[t] ? o : best_c[t];
-                        o = __shfl_xor(best_c[t], 32, 64);
-                        best_c[t] = o > best_c[t] ? o : best_c[t];
-                    }
+                uint64_t o = __shfl_xor(best, 16, 64);
+                best = o > best ? o : best;
+                o = __shfl_xor(best, 32, 64);
+                best = o > best ? o : best;
+                if (two) {
+                    o = __shfl_xor(best_c, 16, 64);
+                    best_c = o > best_c ? o : best_c;
+                    o = __shfl_xor(best_c, 32, 64);
+                    best_c = o > best_c ? o : best_c;
                 }
-            }
-            // one composite per query and panel; a panel without rows leaves the empty composite
-            const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * NW + wave;
-            if (g == 0) {
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    if (16 * t + r < A.m_valid) {
-                        A.cand[(int64_t)(16 * t + r) * A.cand_stride + pidx] = best[t];
-                        if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + pidx] = best_c[t];
-                    }
+                // one composite per query and panel; a panel without rows leaves the empty composite
+                if (eg == 0 && 16 * t + er < A.m_valid) {
+                    A.cand[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best;
+                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best_c;
+                }
             }
         } else if (MODE == MODE_DOTS) {
             const int64_t hi = lo + rows;
@@ -605,7 +639,7 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
 // LDS bytes of a variant
 template <int T, int KW, int NST, int NW>
 constexpr size_t mq_lds_bytes() {
-    return (size_t)(NW * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece;
+    return (size_t)(NW * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece + (size_t)NW * 1024;   // + row norms, query norms
 }
 
 template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
@@ -661,6 +695,9 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
         !mq_waves_available(waves) || (waves == 8 && kw != 64))
         return fail(CSLAM_E_INVALID, "scan_mq: bad launch (tiles %d, slice %d, waves %d, rows %lld)", tiles, kw,
                     waves, (long long)a.n);
+#if defined(CSLAM_MQ_DEV_T5)   // development builds: one variant only (seconds to compile; tools/mq_dev_build.sh)
+    return launch_mode<5, 128, 2, 6, 4>(a, mode, nt, st);
+#else
 #if defined(CSLAM_MQ_WAVES8)
     if (waves == 8) {
         switch (tiles) {
@@ -685,6 +722,7 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
         case 4: return launch_mode<4, 64, 6, 6, 4>(a, mode, nt, st);
         default: return launch_mode<5, 64, 6, 6, 4>(a, mode, nt, st);
     }
+#endif
 }
 
 int launch_mq_combine(const MqArgs& a, int tiles, int nchunks, bool best, int64_t cand_off, hipStream_t st) {
