@@ -128,6 +128,111 @@ def launch_ranks(args):
     return 0
 
 
+class Deadline(object):
+    """`with Deadline(seconds, what):` - a watchdog thread ends THIS process with status 6 when the
+    body has not finished in time (a collective that never completes, a hung device).  Fresh-process
+    semantics only: nothing is re-executed, the parent (launch_ranks) sees the failed rank and stops the rest."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def _expire(self):
+        sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '0')}: '{self.what}' did not finish within "
+                         f"{self.seconds:.0f} s - exiting\n")
+        sys.stderr.flush()
+        os._exit(6)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._expire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def robot_blocks(torch, dev, robot, per_rank, dim):
+    """The 8 blocks of new descriptors robot `robot` cycles through (seeded by the robot alone)."""
+    gb = torch.Generator(device=dev).manual_seed(10_000 + robot)
+    return torch.rand((8, per_rank, dim), device=dev, generator=gb)
+
+
+def selfcheck_exchange(torch, L, _lib, comm, rank, world, nb_robots, dev, out):
+    """Before timing: the communicator counts `world` ranks, and a rank-stamped block gathered through
+    the library's own collective (cslam_comm_allgather) arrives in the right slot on every rank."""
+    loopback = world == 1
+    out["communicator_size"] = "ok" if loopback or comm.size() == world else f"FAILED: {comm.size()} != {world}"
+    n = 1024
+    i = torch.arange(n, dtype=torch.int64, device=dev)
+    send = (rank * 1_000_003 + i * 7919) % 2_147_483_647
+    recv = torch.full((nb_robots * n,), -1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.cslam_comm_allgather(comm.handle, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()),
+                                      n * 8, ctypes.c_void_p(st)))
+    torch.cuda.synchronize()
+    got = recv.view(nb_robots, n).cpu()
+    bad = []
+    for r in range(nb_robots):
+        src = 0 if loopback else r              # the loopback transport replicates the caller's block
+        want = ((src * 1_000_003 + torch.arange(n, dtype=torch.int64) * 7919) % 2_147_483_647)
+        if not torch.equal(got[r], want):
+            bad.append(r)
+    out["stamped_allgather"] = "ok" if not bad else f"FAILED: slots {bad} do not hold their rank's stamp"
+
+
+def selfcheck_records(torch, L, _lib, pool, state, rank, world, nb_robots, per_rank, N, D, dev, stream, out):
+    """After the timed loop: the records THIS rank contributed to the last fetched step are recomputed
+    from scratch - the peers' blocks regenerated from their seeds, one row-range search per window
+    (cslam_pool_search_range_dev) - and compared bit for bit with what came back through the record
+    exchange: content, not count.  (Keyframe id = pool row in this bench.)"""
+    import numpy as np
+    if world == 1:
+        out["last_step_records"] = "skipped (loopback: no peers)"   # every slot is a copy of the own block
+        return
+    recs = state.get("last_records")
+    m = state["fetched"] - 1                      # the step those records belong to
+    if recs is None or m < 0:
+        out["last_step_records"] = "FAILED: no step was fetched"
+        return
+    if os.environ.get("CSLAM_BENCH_SELFCHECK_CORRUPT") == "1":   # tests: prove that the check bites
+        recs = recs.copy()
+        recs["weight"] = recs["weight"] + np.float32(1e-3)
+    n0 = N + m * per_rank                         # pool rows before step m's own block
+    problems = []
+    seen = 0
+    for s_ in range(nb_robots):
+        if s_ == rank:
+            continue
+        q = robot_blocks(torch, dev, s_, per_rank, D)[m % 8].contiguous()
+        res = {}
+        for name, lo, hi in (("old", 0, n0), ("new", n0, n0 + per_rank)):
+            idx = torch.empty((per_rank, 1), dtype=torch.int32, device=dev)
+            sim = torch.empty((per_rank, 1), dtype=torch.float32, device=dev)
+            _lib.check(L.cslam_pool_search_range_dev(pool.handle, ctypes.c_void_p(q.data_ptr()), D, per_rank, 1, lo, hi,
+                                                     ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()),
+                                                     ctypes.c_void_p(stream)))
+            torch.cuda.synchronize()
+            res[name] = (idx[:, 0].cpu().numpy(), sim[:, 0].cpu().numpy())
+        for j in range(per_rank):
+            kf_s = N + m * per_rank + j
+            ia, sa = int(res["old"][0][j]), res["old"][1][j]
+            ic, sc = int(res["new"][0][j]), res["new"][1][j]
+            want = [(rank, ia, s_, kf_s, sa)]                             # lcsm.py:58-76, r0 slot
+            if ic >= 0 and not (ia >= 0 and sa >= sc):
+                want.append((s_, kf_s, rank, ic, sc))                     # lcsm.py:37-56 on the peer's behalf
+            for w in want:
+                hit = recs[(recs["robot0_id"] == w[0]) & (recs["robot0_keyframe_id"] == w[1]) &
+                           (recs["robot1_id"] == w[2]) & (recs["robot1_keyframe_id"] == w[3])]
+                seen += 1
+                if len(hit) != 1 or np.float32(hit["weight"][0]).tobytes() != np.float32(w[4]).tobytes():
+                    problems.append((w, [tuple(h) for h in hit][:2]))
+    out["last_step_records"] = "ok" if not problems and seen >= (nb_robots - 1) * per_rank else \
+        f"FAILED: {len(problems)} of {seen} recomputed records differ, e.g. {problems[:2]}"
+
+
 def main():
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
@@ -174,7 +279,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(rank)
     X = torch.rand((N, D), device=dev, generator=g)
     X /= X.norm(dim=1, keepdim=True)
-    grow = (total_steps + 80) * per_rank if nb_robots > 1 else 0
+    grow = (total_steps + 90) * per_rank if nb_robots > 1 else 0
     pool = NearestNeighborsMatching(dim=D, device_id=local_rank, capacity_hint=N + grow)
     stream = torch.cuda.current_stream().cuda_stream
     pool.add_items_device(X.data_ptr(), N, D, items=None, stream=stream)
@@ -223,7 +328,9 @@ def main():
         # CSLAM_BENCH_INTRA=1 adds match_local_loop_closures (nb_best_matches = 10, lcsm.py:78-97).
         shard = DeviceShard(pool, rank, nb_robots, per_rank, 0.0, comm, comm,
                             nb_best_matches=10 if intra else 0, intra_min_inbetween=10)
-        blocks = torch.rand((8, per_rank, D), device=dev, generator=g)   # new keyframes, cycled
+        # new keyframes, cycled; from a generator of their own so that ANY rank can regenerate what rank r
+        # publishes (the self-check below recomputes the last step's records from it)
+        blocks = robot_blocks(torch, dev, rank, per_rank, D)
         next_kf = [N]
         torch.cuda.synchronize()
         # new descriptors come from the front end's stream (the VPR network), not from the
@@ -237,22 +344,39 @@ def main():
             shard.publish(blocks[state["published"] % 8], kfs, front.cuda_stream)
             state["published"] += 1
 
+        # exchanges in flight ahead of the scan (1 = the exchange of step t+1 overlaps the scan of step t)
+        # 2 (default): the exchange of step t+2 is queued while step t is scanned, so that by the time the
+        # host queues match(t+1) the event of publish(t+1) has completed and no cross-stream barrier packet
+        # goes in front of the scan (~5 us per step on the cfg4 workload, profiles/r04_bench_cfg4_ab.txt)
+        ahead = max(1, min(2, int(os.environ.get("CSLAM_BENCH_PUBLISH_AHEAD", "2"))))
+
+        def fetch():
+            recs = shard.fetch_records()
+            state["records"] += len(recs)
+            state["last_records"] = recs           # of step state["fetched"]
+            state["fetched"] += 1
+
         def step(t):
             # exchange of step t+1 first (own stream), then step t's scan + records;
             # the records of step t-1 are fetched while step t runs
-            if state["published"] == state["matched"]:
+            while state["published"] - state["matched"] < ahead:
                 publish()
             publish()
             shard.match(stream)
             state["matched"] += 1
             if state["matched"] - state["fetched"] > 1:
-                state["records"] += len(shard.fetch_records())
-                state["fetched"] += 1
+                fetch()
 
         def drain():
             while state["fetched"] < state["matched"]:
-                state["records"] += len(shard.fetch_records())
-                state["fetched"] += 1
+                fetch()
+
+        # first N > 1 run on hardware validates itself: communicator size, a rank-stamped all-gather
+        # compared on every rank - BEFORE anything is timed, under a deadline (a collective that does
+        # not complete makes this rank exit non-zero; the parent then stops the others)
+        selfcheck = {"communicator_size": None, "stamped_allgather": None, "last_step_records": None}
+        with Deadline(float(os.environ.get("CSLAM_BENCH_SELFCHECK_DEADLINE_S", "180")), "self-check all-gather"):
+            selfcheck_exchange(torch, L, _lib, comm, rank, world, nb_robots, dev, selfcheck)
 
     def fence():
         if world > 1:
@@ -288,7 +412,19 @@ def main():
     scan_ms = ctypes.c_double()
     n_l = ctypes.c_int()
     _lib.check(L.cslam_pool_profile_end(pool.handle, ctypes.byref(scan_ms), ctypes.byref(n_l)))
+    scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()   # of the timed steps (the self-check below searches too)
 
+    if nb_robots > 1:
+        with Deadline(float(os.environ.get("CSLAM_BENCH_SELFCHECK_DEADLINE_S", "180")), "self-check of the last step's records"):
+            selfcheck_records(torch, L, _lib, pool, state, rank, world, nb_robots, per_rank, N, D, dev, stream,
+                              selfcheck)
+        if world > 1:       # every rank must agree before a number is printed
+            oks = [None] * world
+            dist.all_gather_object(oks, selfcheck)
+            bad = [(r, o) for r, o in enumerate(oks) if any(v not in ("ok", "skipped (loopback: no peers)") for v in o.values())]
+            if bad:
+                sys.stderr.write(f"bench.py: self-check FAILED on rank(s) {bad}\n")
+                sys.exit(5)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # gloo, host tensor
@@ -304,7 +440,9 @@ def main():
                      "collectives_per_step": (sd["collectives"] - coll0) / args.steps,
                      "match_records_per_step": state["records"] / args.steps,
                      "new_descriptors_per_rank_per_step": per_rank,
-                     "gathered_descriptors_per_step": gathered_rows}
+                     "gathered_descriptors_per_step": gathered_rows,
+                     "selfcheck": "ok" if all(v in ("ok", "skipped (loopback: no peers)") for v in selfcheck.values()) else "FAILED",
+                     "selfcheck_detail": selfcheck}
 
     ms_per_step = dt / args.steps * 1e3
     # candidates evaluated per step: N = 1 (cfg2) all 16 best-match evaluations; sharded step: the
@@ -315,7 +453,6 @@ def main():
 
     # scan kernel roofline: algorithmic bytes / flops of one launch:
     #   pool rows N*D*4 + queries M*D*4 + results M*k*8;  2*N*D*M flop
-    scan_kernel = L.cslam_pool_scan_kernel(pool.handle).decode()
     n_rows_scanned = N if nb_robots == 1 else N + (settle + args.warmup + args.steps // 2) * per_rank
     k_sel = 1 if nb_robots == 1 else (per_rank + 10 if intra else 2)
     alg_bytes = n_rows_scanned * D * 4 + gathered_rows * D * 4 + gathered_rows * k_sel * 8

@@ -2022,6 +2022,7 @@ int mq_pass_queries(int left) {
 // to a scratch array) and a combine launch that folds those in chunk order (same bits).
 struct MqPlan {
     int tiles, kw, waves, n_blocks, p_max;
+    int part_kw, part_waves;   // slice width and waves per block of the K-split launch
     int64_t n_main;      // rows of the main launch (all of them when there is no tail)
     int tail_groups, tail_ks, nchunks;   // K-split tail: strip groups x K parts
     int64_t tail_strips;
@@ -2039,6 +2040,8 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
     static Knob k_waves{"CSLAM_MQ_WAVES", 4};   // A/B: 8 = two waves per SIMD (builds with -DCSLAM_MQ_WAVES8 only)
     g.waves = knob(k_waves) == 8 && mq_waves_available(8) ? 8 : 4;
     if (g.waves == 8) g.kw = 64;                // eight private rings fit the LDS with 4-KiB stages only
+    g.part_kw = g.kw;
+    g.part_waves = g.waves;
     g.nchunks = (p->dp + 511) / 512;
     const int ns = mq_panel_strips(g.tiles, g.waves);
     const int64_t strips = (vn + 15) / 16;
@@ -2106,15 +2109,69 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
             g.tail_ks = (int)best_ks;
         }
     }
-    // A/B and measurement: the WHOLE window through the K-split launch + combine, as `groups` strip
-    // groups x `ks` K parts ("groups,ks"; no main launch)
+    // THE WHOLE WINDOW THROUGH THE K-SPLIT LAUNCH (round 4): no main launch; (strip, 512-float chunk)
+    // units dealt over all waves of ONE wave of blocks - groups x ks <= CUs - and folded by
+    // k_mq_combine.  A pool of few strips per wave loses whole strip times to quantisation (25 000
+    // rows: 1563 strips = two per wave on 784 waves where 1.53 would do; as 32 groups x 8 K parts
+    // the busiest wave has 13 units of 12.2 = 1.625 strip times) and the K-split kernel carries
+    // no running totals (half the accumulators, no fold arithmetic).  Against that: every chunk
+    // partial travels through memory - T / 32 of the pool's bytes written and read again (+31 % HBM
+    // traffic at five tiles, which a matrix-pipe-bound pass has room for) - and one more launch.
+    // Measured, 80 queries x 4096-d, kernel time of the pass (profiles/r04_mq_plan_ab_*.txt):
+    //   12 000 rows 122 -> 81 us, 25 000: 200 -> 164, 40 000: 266 -> 237, 60 000: 364 -> 359-364,
+    //   100 000: 553 -> 590: taken up to 3.3 strips per wave, from three query tiles on (two tiles
+    //   lean on the HBM, where the extra traffic costs what the quantisation saves).
+    // CSLAM_MQ_ALLPART=0: never; =2: whenever a split exists (A/B).  CSLAM_MQ_ALLPART_GROUPS / _KS force one.
+    static Knob k_allpart{"CSLAM_MQ_ALLPART", 1};
     static Knob k_allpart_g{"CSLAM_MQ_ALLPART_GROUPS", 0};
     static Knob k_allpart_k{"CSLAM_MQ_ALLPART_KS", 0};
+    const int64_t most_groups = (strips + g.waves - 1) / g.waves;   // a strip per wave at least
     if (knob(k_allpart_g) > 0 && knob(k_allpart_k) > 0 && knob(k_allpart_k) <= g.nchunks) {
         g.n_main = 0;
         g.tail_strips = strips;
-        g.tail_groups = (int)std::min<int64_t>(knob(k_allpart_g), (strips + g.waves - 1) / g.waves);
+        g.tail_groups = (int)std::min<int64_t>(knob(k_allpart_g), most_groups);
         g.tail_ks = knob(k_allpart_k);
+    } else if (knob(k_allpart) != 0 && knob(k_tail) && strips > 0 &&
+               ((g.tiles >= 3 && 10 * strips <= 33 * (int64_t)g.waves * p->cus) || knob(k_allpart) == 2)) {
+        // TWO WAVES PER SIMD for this launch (CSLAM_MQ_PART_WAVES=4: one): the K-split kernel carries no
+        // running totals, so eight waves of <= 256 registers fit a CU (64-float slices: eight private
+        // rings of 4-KiB stages), and the partner wave's MFMAs fill what one wave per SIMD leaves idle at
+        // every stage boundary, LDS wait and barrier (in-kernel clock probe: 40 clocks per MFMA with one
+        // wave per SIMD, 36 inside the k-blocks, against 32 of the pipe; profiles/r04_mq_clock_probe_1.txt).
+        static Knob k_part_waves{"CSLAM_MQ_PART_WAVES", 8};
+        const int pw = knob(k_part_waves) == 8 && p->dp % 64 == 0 ? 8 : g.waves;
+        const int64_t most = (strips + pw - 1) / pw;
+        // the split with the fewest units on the busiest wave; among equals the fewest K parts
+        // (longer rounds, fewer partial stores per step: 40 000 rows 237 us as 64 x 4 or 128 x 2, 245 as 32 x 8)
+        int64_t best_u = INT64_MAX, bg = 0, bk = 0;
+        for (int64_t k = 1; k <= g.nchunks; ++k) {
+            int64_t groups = std::min<int64_t>(p->cus / k, most);
+            if (groups < 1) continue;
+            const int64_t spb = (strips + groups - 1) / groups;
+            const int64_t spw = (spb + pw - 1) / pw;
+            const int64_t cpb = (g.nchunks + k - 1) / k;
+            // units per SIMD: the waves of a SIMD (pw / 4) take spw strips at most each
+            if (spw * cpb * (pw / 4) < best_u) {
+                best_u = spw * cpb * (pw / 4);
+                bg = groups;
+                bk = k;
+            }
+        }
+        // units of the plan made above: whole strips in the main launch + the tail's
+        const int64_t q_units = (g.tail_strips > 0 ? q : q + (tail > 0 ? 1 : 0)) * g.nchunks;
+        int64_t tail_units = 0;
+        if (g.tail_strips > 0) {
+            const int64_t spb = (g.tail_strips + g.tail_groups - 1) / g.tail_groups;
+            tail_units = ((spb + g.waves - 1) / g.waves) * ((g.nchunks + g.tail_ks - 1) / g.tail_ks);
+        }
+        if (bg > 0 && (best_u <= q_units + tail_units + (pw == 8 ? 1 : 0) || knob(k_allpart) == 2)) {
+            g.n_main = 0;
+            g.tail_strips = strips;
+            g.tail_groups = (int)bg;
+            g.tail_ks = (int)bk;
+            g.part_waves = pw;
+            if (pw == 8) g.part_kw = 64;
+        }
     }
     const int64_t strips_main = (g.n_main + 15) / 16;
     // A wave's time is its number of whole strips: 1563 strips need two per wave on 256 CUs (6 or 7 per
@@ -2153,6 +2210,18 @@ const char* mq_name(const MqPlan& g, bool best) {
           "k_scan_mq<T=5,KW=64,NST=3,NW=8>"},
          {"k_scan_mq<T=2,KW=64,NST=4,NW=8,best>", "k_scan_mq<T=3,KW=64,NST=3,NW=8,best>",
           "k_scan_mq<T=4,KW=64,NST=3,NW=8,best>", "k_scan_mq<T=5,KW=64,NST=3,NW=8,best>"}}};
+    if (g.n_main == 0 && g.tail_strips > 0) {   // the whole window through the K-split launch + k_mq_combine
+        static const char* const part[2][2][4] = {
+            {{"k_scan_mq<T=2,KW=64,NST=3,NW=8,part> + k_mq_combine", "k_scan_mq<T=3,KW=64,NST=3,NW=8,part> + k_mq_combine",
+              "k_scan_mq<T=4,KW=64,NST=3,NW=8,part> + k_mq_combine", "k_scan_mq<T=5,KW=64,NST=3,NW=8,part> + k_mq_combine"},
+             {"k_scan_mq<T=2,KW=64,NST=3,NW=8,part> + k_mq_combine<best>", "k_scan_mq<T=3,KW=64,NST=3,NW=8,part> + k_mq_combine<best>",
+              "k_scan_mq<T=4,KW=64,NST=3,NW=8,part> + k_mq_combine<best>", "k_scan_mq<T=5,KW=64,NST=3,NW=8,part> + k_mq_combine<best>"}},
+            {{"k_scan_mq<T=2,NW=4,part> + k_mq_combine", "k_scan_mq<T=3,NW=4,part> + k_mq_combine",
+              "k_scan_mq<T=4,NW=4,part> + k_mq_combine", "k_scan_mq<T=5,NW=4,part> + k_mq_combine"},
+             {"k_scan_mq<T=2,NW=4,part> + k_mq_combine<best>", "k_scan_mq<T=3,NW=4,part> + k_mq_combine<best>",
+              "k_scan_mq<T=4,NW=4,part> + k_mq_combine<best>", "k_scan_mq<T=5,NW=4,part> + k_mq_combine<best>"}}};
+        return part[g.part_waves == 8 ? 0 : 1][best ? 1 : 0][g.tiles - 2];
+    }
     return names[g.waves == 8 ? 2 : (g.kw == 128 ? 0 : 1)][best ? 1 : 0][g.tiles - 2];
 }
 // stage `m` queries (17..80) and scan the window [v0, v0 + vn): raw dots, or (best) one composite
@@ -2206,7 +2275,7 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         b.p_max = 1;
         b.part = p->part.as<f32x4>();
         b.part_ks = g.tail_ks;
-        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.kw, g.waves, kMqModePart, false, st));
+        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.part_kw, g.part_waves, kMqModePart, false, st));
         CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * g.waves, st));
     }
     if (prof) {
@@ -3014,6 +3083,11 @@ int pool_order_on(cslam_pool_t* p, hipStream_t st) {
 int pool_mq_free_cus(const cslam_pool_t* p, int m, int64_t rows) {
     if (!p || rows <= 0 || m <= 16 || m > 16 * mq_max_tiles() || p->dp % 64 != 0) return 0;
     const MqPlan g = mq_plan(p, m, rows, 1);   // as the shard's match() will plan it
+    // The all-K-split pass puts a block on every CU, but its waves take well under half of a SIMD's
+    // registers (188-224 of 512): the exchange stream's small kernels run beside it (measured: pack,
+    // append, unpack of the next step inside the 151-us scan, profiles/r04_bench_cfg4_timeline.txt) -
+    // reported as an eighth of the chip, enough for the caller to stage at publish time.
+    if (g.n_main == 0 && g.tail_strips > 0) return p->cus / 8;
     return g.tail_strips == 0 && g.n_main > 0 ? p->cus - g.n_blocks : 0;
 }
 int64_t pool_staged_floats(const cslam_pool_t* p, int m) {

@@ -540,10 +540,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 #if defined(CSLAM_MQ_PROBE_CLOCK)
     {
         const uint64_t dt = __builtin_amdgcn_s_memtime() - pc_t0, dr = __builtin_amdgcn_s_memrealtime() - pc_r0;
-        if ((blockIdx.x == 3 || blockIdx.x == 100) && threadIdx.x == 0 && MODE != MODE_PART)
-            printf("mq clock probe: block %d T=%d NW=%d: %llu shader cycles in %llu x 10 ns = %.3f GHz, %.1f cycles per MFMA; "
+        if ((blockIdx.x == 3 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && wave == 0)
+            printf("mq clock probe: block %d mode %d stages %d T=%d NW=%d: %llu shader cycles in %llu x 10 ns = %.3f GHz, %.1f cycles per MFMA; "
                    "of them waiting for B %llu, at the barrier %llu (%d steps), inside the k-block loops of the stages %llu\n",
-                   (int)blockIdx.x, T, NW, (unsigned long long)dt, (unsigned long long)dr, (double)dt / (10.0 * dr),
+                   (int)blockIdx.x, MODE, J, T, NW, (unsigned long long)dt, (unsigned long long)dr, (double)dt / (10.0 * dr),
                    (double)dt / ((double)J * NB * 4 * T), (unsigned long long)pc_wait_b, (unsigned long long)pc_wait_bar, gstep,
                    (unsigned long long)pc_body);
     }
@@ -677,7 +677,7 @@ namespace cslam {
 // (0.567 vs 0.560 ms for 80 queries x 100k x 4096-d, 0.322 vs 0.310 for 32), so it is only
 // compiled with -DCSLAM_MQ_WAVES8 (CSLAM_MQ_WAVES=8 then selects it, A/B runs).
 int mq_max_tiles() { return 5; }
-int mq_waves_available(int waves) {
+int mq_waves_available(int waves) {   // for the main launch; the K-split launch always has its eight-wave form
 #if defined(CSLAM_MQ_WAVES8)
     return waves == 8 || waves == 4;
 #else
@@ -691,6 +691,17 @@ int mq_panel_strips(int tiles, int waves) {
 
 int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool nt, hipStream_t st) {
     if (mode == kMqModePart && a.part_ks < 1) return fail(CSLAM_E_INVALID, "scan_mq: K parts");
+    // The K-split launch with two waves per SIMD (eight private rings of 4-KiB stages, 64-float slices):
+    // no running totals, so NS strips x T tiles of accumulators fit 256 registers per wave
+    if (mode == kMqModePart && waves == 8 && kw == 64 && tiles >= 2 && tiles <= 5 && a.dp % 64 == 0 && a.n > 0 &&
+        a.n_blocks >= 1) {
+        switch (tiles) {
+            case 2: return launch_one<2, 64, 3, 8, 0, MODE_PART, 8>(a, st);
+            case 3: return launch_one<3, 64, 3, 8, 0, MODE_PART, 8>(a, st);
+            case 4: return launch_one<4, 64, 3, 6, 0, MODE_PART, 8>(a, st);
+            default: return launch_one<5, 64, 3, 6, 0, MODE_PART, 8>(a, st);
+        }
+    }
     if (tiles < 2 || tiles > 5 || (kw != 128 && kw != 64) || a.dp % kw != 0 || a.n <= 0 || a.n_blocks < 1 ||
         !mq_waves_available(waves) || (waves == 8 && kw != 64))
         return fail(CSLAM_E_INVALID, "scan_mq: bad launch (tiles %d, slice %d, waves %d, rows %lld)", tiles, kw,

@@ -45,6 +45,9 @@ def test_bench_self_launches_two_ranks(gpu):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "robot-per-gpu x2"
     dist = d["dist"]
     assert dist["world_size"] == 2 and dist["control_plane_backend"] == "gloo" and dist["communicators"] == 1
+    # the first N > 1 run validates itself: communicator size, rank-stamped all-gather, the last step's
+    # records recomputed from the regenerated peer blocks and compared bit for bit
+    assert dist["selfcheck"] == "ok" and set(dist["selfcheck_detail"].values()) == {"ok"}, dist
     # ONE all-gather of blocks + ids at publish time, ONE of the records at match time
     assert dist["new_descriptors_per_rank_per_step"] == 8 and abs(dist["collectives_per_step"] - 2) < 0.5
     # threshold 0 on non-negative data: every foreign descriptor matches its best old row, every own
@@ -75,3 +78,16 @@ def test_bench_cfg4_workload_on_one_gpu(gpu):
     r = d["roofline"]
     assert r["kernel"].startswith("k_scan_mq<T=5") and r["kernel"].endswith("best>")
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+def test_bench_self_check_bites(gpu):
+    """A record that differs from its recomputation ends the run non-zero on every rank, no JSON line."""
+    env = dict(os.environ, CSLAM_BENCH_SAME_DEVICE="1", CSLAM_BENCH_BACKEND="gloo", CSLAM_BENCH_SELFCHECK_CORRUPT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--keyframes", "6000", "--dim",
+                          "256", "--steps", "6", "--warmup", "2"], env=env, timeout=300, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    assert out.returncode != 0
+    assert "self-check FAILED" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

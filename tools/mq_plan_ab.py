@@ -13,13 +13,12 @@ L = _lib.load(); D = 4096
 MS = [int(x) for x in os.environ.get("MQ_M", "80").split(",")]
 sizes = [int(a) for a in sys.argv[1:]] or [25000, 100000, 60000, 12000, 5000]
 SETTINGS = [
-    ("round-3 rule (rounds of one-strip-per-wave blocks)", {"CSLAM_MQ_TAIL_SHAPE": "2"}),
-    ("round-4 rule (default)", {}),
-    ("one wave of blocks only", {"CSLAM_MQ_TAIL_SHAPE": "1"}),
-    ("no tail launch", {"CSLAM_MQ_TAIL": "0"}),
-    ("all K-split 32 x 8", {"CSLAM_MQ_ALLPART_GROUPS": "32", "CSLAM_MQ_ALLPART_KS": "8"}),
-    ("all K-split 64 x 4", {"CSLAM_MQ_ALLPART_GROUPS": "64", "CSLAM_MQ_ALLPART_KS": "4"}),
-    ("all K-split 128 x 2", {"CSLAM_MQ_ALLPART_GROUPS": "128", "CSLAM_MQ_ALLPART_KS": "2"}),
+    ("round-3 rule (rounds of one-strip-per-wave blocks)", {"CSLAM_MQ_TAIL_SHAPE": "2", "CSLAM_MQ_ALLPART": "0"}),
+    ("main + one wave of tail blocks, no all-K-split", {"CSLAM_MQ_ALLPART": "0"}),
+    ("round-4 default", {}),
+    ("all-K-split with one wave per SIMD", {"CSLAM_MQ_PART_WAVES": "4"}),
+    ("all-K-split forced, two waves per SIMD", {"CSLAM_MQ_ALLPART": "2"}),
+    ("all-K-split forced, one wave per SIMD", {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_PART_WAVES": "4"}),
 ]
 KEYS = sorted({k for _, e in SETTINGS for k in e})
 g = torch.Generator(device="cuda").manual_seed(0)
