@@ -16,6 +16,7 @@
 //                   (similarity desc, row asc) composites, wave-shuffle + LDS reduction
 //   k_bitonic_step  any k: full bitonic sort of the composites in HBM (rare path)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,7 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
+#include "probe_hooks.hpp"
 
 using namespace cslam;
 
@@ -432,10 +434,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece, kStage = GM::kStage;
     static_assert(NS == 8 && NS % R == 0, "a panel is 8 row groups");
-#if defined(CSLAM_DMA_PROBE_CLOCK)   // timing probe (tools/build_mq_probes.sh): where a wave's time goes
-    const uint64_t pc_r0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t pc_r1 = 0, pc_r2 = 0;
-#endif
+    CSLAM_DMA_HOOK_KERNEL_BEGIN
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     // the query norms are computed here when the epilogue needs them (BEST) or when the caller
     // skipped the staging kernel and wants them for the select (rnq_out)
@@ -535,9 +534,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     };
     load_b<NB>(bn, qrow);
     wait0_tie_b<NB>(bn);
-#if defined(CSLAM_DMA_PROBE_CLOCK)
-    pc_r1 = __builtin_amdgcn_s_memrealtime();
-#endif
+    CSLAM_DMA_HOOK_QUERIES_LANDED
     // (Round 3 tried once more to request the first stages IN FRONT of this wait, for pools of a few
     // strips per wave - the time line of a 25 000 x 4096-d scan is 2.6-3.2 us until the queries have
     // landed, 2.5-3.5 more until the first stage has, then 66 us of streaming,
@@ -616,9 +613,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
 #pragma unroll
                     for (int i = 1; i < NST; ++i) yc = slot == i ? y[i] : yc;
                     wait_vm_dyn(yc);  // this stage's pieces have landed
-#if defined(CSLAM_DMA_PROBE_CLOCK)
-                    if (pc_r2 == 0) pc_r2 = __builtin_amdgcn_s_memrealtime();
-#endif
+                    CSLAM_DMA_HOOK_STAGE_LANDED
                     f32x4 a[16];
                     const char* ap = sp + rd_off;
 #pragma unroll
@@ -750,14 +745,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         cand[(int64_t)r * cand_stride + w] = wbest_a;
         if (cand_c != nullptr) cand_c[(int64_t)r * cand_stride + w] = wbest_c;
     }
-#if defined(CSLAM_DMA_PROBE_CLOCK)
-    if (lane == 0 && (w % 97) == 0) {
-        const uint64_t r3 = __builtin_amdgcn_s_memrealtime();
-        printf("dma probe: wave %4d rows %lld: entry %llu (x10 ns, absolute), queries landed +%llu, first stage landed +%llu, done +%llu\n",
-               w, (long long)(whi - wlo), (unsigned long long)(pc_r0 % 100000000ull), (unsigned long long)(pc_r1 - pc_r0),
-               (unsigned long long)(pc_r2 - pc_r0), (unsigned long long)(r3 - pc_r0));
-    }
-#endif
+    CSLAM_DMA_HOOK_KERNEL_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1661,19 +1649,23 @@ struct cslam_pool {
     hipEvent_t app_ev = nullptr;
     hipStream_t app_stream = nullptr;
     bool app_pending = false;
-    // set by the shard around ITS OWN searches (pool_internal_scope): they run on explicit row
-    // windows behind the publish event of their own step and must not wait for the append of a
-    // LATER step, which the pipelined exchange has already queued
-    bool internal_caller = false;
 };
 
 namespace {
+
+// The pool whose searches the CALLING THREAD is running as the shard (PoolInternalScope, shard.hip):
+// they work on the explicit row windows of their own step, behind that step's publish event, and must
+// not wait for the append of a LATER step that the pipelined exchange has already queued.  Per thread
+// and per pool (round 3 kept a flag on the shared pool object: another thread's host-API search on the
+// same pool skipped its ordering while a shard was matching - ADVICE r03).
+thread_local const cslam_pool* tls_shard_scope = nullptr;
+inline bool shard_scope(const cslam_pool* p) { return tls_shard_scope == p; }
 
 // make `st` wait for the last device-API work enqueued on another stream
 int order_after_dev(cslam_pool* p, hipStream_t st) {
     if (p->dev_pending && p->dev_stream != st)
         CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->dev_ev, 0));
-    if (p->app_pending && p->app_stream != st && !p->internal_caller) {
+    if (p->app_pending && p->app_stream != st && !shard_scope(p)) {
         // the append was issued a whole step ahead of the scan that needs it: normally it is
         // complete, and then the stream is spared the cross-stream barrier packet (~10 us in
         // front of a scan, profiles/r02_shard_step_timeline.txt)
@@ -1770,20 +1762,27 @@ bool dma_scan_applies(const cslam_pool* p) {
 // measurement knobs: read once — or at every launch when CSLAM_KNOBS_LIVE is set, so that a tool can
 // alternate settings inside one process (tools/reserve_ab.py; boxes and processes differ by
 // more than the effects in question)
+// Measurement / A-B knobs (environment variables): read ONCE per process, then cached.  Two ways to have
+// them read again, both for tests and tools only: cslam_knobs_reload() (every knob re-reads its variable
+// at its next use: a test changes one setting, reloads, and reloads again when it restores the
+// environment) and CSLAM_KNOBS_LIVE (every use re-reads: tools that alternate settings launch by
+// launch).  Fields are atomics: shards run as threads of one process (tests/test_shard_gpu.py).
+std::atomic<int> g_knob_generation{1};
 struct Knob {
     const char* name;
     int def;
-    int value = 0;
-    bool init = false;
+    std::atomic<int> value{0};
+    std::atomic<int> generation{0};
 };
 int knob(Knob& k) {
     static const bool live = getenv("CSLAM_KNOBS_LIVE") != nullptr;
-    if (live || !k.init) {
+    const int g = g_knob_generation.load(std::memory_order_relaxed);
+    if (live || k.generation.load(std::memory_order_acquire) != g) {
         const char* s = getenv(k.name);
-        k.value = s ? atoi(s) : k.def;
-        k.init = true;
+        k.value.store(s ? atoi(s) : k.def, std::memory_order_relaxed);
+        k.generation.store(g, std::memory_order_release);
     }
-    return k.value;
+    return k.value.load(std::memory_order_relaxed);
 }
 
 // small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
@@ -2184,7 +2183,7 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
     // Two tiles lean on the HBM and lose 4-6 % of kernel time on fewer CUs: packed only for the shard's
     // own searches, where the exchange stream's kernels beside the scan are worth more (30 gathered
     // descriptors x 25 000 rows: 0.131-0.133 -> 0.126-0.127 ms per step), or with CSLAM_MQ_PACK_BLOCKS=2.
-    const bool shard = shard_caller >= 0 ? shard_caller != 0 : p->internal_caller;
+    const bool shard = shard_caller >= 0 ? shard_caller != 0 : shard_scope(p);
     if (knob(k_pack) && strips_main > 0 && (g.tiles >= 3 || shard || knob(k_pack) == 2)) {
         const int64_t per_wave = (strips_main + (int64_t)g.waves * g.n_blocks - 1) / ((int64_t)g.waves * g.n_blocks);
         const int64_t blocks = (strips_main + g.waves * per_wave - 1) / (g.waves * per_wave);
@@ -3029,6 +3028,12 @@ int cslam_pool_profile_begin_sampled(cslam_pool_t* p, int max_samples, int every
     return CSLAM_OK;
 }
 
+
+int cslam_knobs_reload(void) {
+    g_knob_generation.fetch_add(1, std::memory_order_acq_rel);
+    return CSLAM_OK;
+}
+
 const char* cslam_pool_scan_kernel(const cslam_pool_t* p) { return p ? p->last_scan_kernel : ""; }
 
 int cslam_pool_profile_end(cslam_pool_t* p, double* avg_scan_ms, int* n_launches) {
@@ -3072,7 +3077,7 @@ int pool_append_on(cslam_pool_t* p, const float* rows_dev, int64_t n_rows, int64
     return CSLAM_OK;
 }
 void pool_internal_scope(cslam_pool_t* p, bool on) {
-    if (p) p->internal_caller = on;
+    tls_shard_scope = on ? p : nullptr;
 }
 int pool_order_on(cslam_pool_t* p, hipStream_t st) {
     if (!p) return fail(CSLAM_E_INVALID, "pool_order_on: null");

@@ -36,6 +36,7 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
+#include "probe_hooks.hpp"
 
 using namespace cslam;
 
@@ -258,10 +259,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 
     int slot = 0;      // ring slot of the stage the consumer is at
     int gstep = 0;
-#if defined(CSLAM_MQ_PROBE_CLOCK)   // timing probe: shader clock held inside the stage loop
-    const uint64_t pc_t0 = __builtin_amdgcn_s_memtime(), pc_r0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t pc_wait_b = 0, pc_wait_bar = 0, pc_body = 0;
-#endif
+    CSLAM_MQ_HOOK_KERNEL_BEGIN
     for (int rd = 0; rd < P; ++rd) {
         const int rows = panel_rows(rd);
         const int64_t lo = panel_lo(NW * rd + wave);
@@ -281,19 +279,12 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             const int bb = gstep & 1;
             // my B pieces of this slice have landed ... and so have everybody's; everybody is also
             // done with the other buffer (slice kc - 1)
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-            const uint64_t pc_b0 = __builtin_amdgcn_s_memtime();
-#endif
+            CSLAM_MQ_HOOK_STEP_BEGIN
             wait_vm_dyn(issued - mark_b);
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-            const uint64_t pc_b1 = __builtin_amdgcn_s_memtime();
-#endif
+            CSLAM_MQ_HOOK_B_LANDED
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-            pc_wait_b += pc_b1 - pc_b0;
-            pc_wait_bar += __builtin_amdgcn_s_memtime() - pc_b1;
-#endif
+            CSLAM_MQ_HOOK_BARRIER_PASSED
             if (MODE == MODE_BEST) {
                 // 1/||x|| of the panel's <= 128 rows for the epilogue: lane l moves the norms of rows
                 // lo + l and lo + 64 + l (clamped into the window) into the wave's LDS area, two 256-B
@@ -334,9 +325,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     // order, so every read of the slot has returned before anything overwrites it.
                     const int nslot = slot + 1 == NST ? 0 : slot + 1;
                     const char* nx = ring + nslot * kStage + rd_off;
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-                    const uint64_t pc_s0 = __builtin_amdgcn_s_memtime();
-#endif
+                    CSLAM_MQ_HOOK_STAGE_BEGIN
                     if (PF && s == 0) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage);
@@ -378,13 +367,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
-#if defined(CSLAM_MQ_PROBE_NO_MFMA)   // timing probe (tools/build_mq_probes.sh): operands consumed, no matrix work
-                            asm volatile("" ::"v"(a[i]), "v"(bcur[t]));
-#else
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], bcur[t][j], acc[s][t], 0, 0, 0);
-#endif
+                                acc[s][t] = CSLAM_MQ_MFMA(a[i][j], bcur[t][j], acc[s][t]);
                             __builtin_amdgcn_sched_barrier(0);
                             if (PF && t == 0) {
                                 // The next k-block's B fragments, requested BEHIND the first chain: hipcc
@@ -397,13 +382,11 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                                     bnx[t2] = *reinterpret_cast<const f32x4*>(bs + t2 * kStage + (i + 1 < NB ? i + 1 : 0) * 64);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-#if !defined(CSLAM_MQ_PROBE_NO_DMA)    // timing probe: the ring is never refilled (wrong results)
                             // the refill's DMA issues between the first chains of the k-block
-                            if (t < PPK && PPK * i + t < NP) {
+                            if (CSLAM_MQ_REFILL && t < PPK && PPK * i + t < NP) {
                                 issue_piece(PPK * i + t, slot);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-#endif
                             // ... and, in the step's first stage, the next slice's B pieces behind the others
                             if (s == 0 && t >= PPK && i + NB * (t - PPK) < NBPX) {
                                 issue_b_piece(i + NB * (t - PPK), kc_nx, bb ^ 1);
@@ -419,9 +402,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                             for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
                         }
                     });
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-                    pc_body += __builtin_amdgcn_s_memtime() - pc_s0;
-#endif
+                    CSLAM_MQ_HOOK_STAGE_END
                     issued += NP;
                     if (s == 0) mark_b = issued;   // an upper bound of the last B piece's position: a longer wait at worst
                     i_advance();
@@ -537,17 +518,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             }
         }
     }
-#if defined(CSLAM_MQ_PROBE_CLOCK)
-    {
-        const uint64_t dt = __builtin_amdgcn_s_memtime() - pc_t0, dr = __builtin_amdgcn_s_memrealtime() - pc_r0;
-        if ((blockIdx.x == 3 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && wave == 0)
-            printf("mq clock probe: block %d mode %d stages %d T=%d NW=%d: %llu shader cycles in %llu x 10 ns = %.3f GHz, %.1f cycles per MFMA; "
-                   "of them waiting for B %llu, at the barrier %llu (%d steps), inside the k-block loops of the stages %llu\n",
-                   (int)blockIdx.x, MODE, J, T, NW, (unsigned long long)dt, (unsigned long long)dr, (double)dt / (10.0 * dr),
-                   (double)dt / ((double)J * NB * 4 * T), (unsigned long long)pc_wait_b, (unsigned long long)pc_wait_bar, gstep,
-                   (unsigned long long)pc_body);
-    }
-#endif
+    CSLAM_MQ_HOOK_KERNEL_END
     if (MODE == MODE_BEST && g == 0) {   // rounds this block does not have (blocks differ by one row)
         for (int rd = P; rd < A.p_max; ++rd) {
             const int64_t pidx = ((int64_t)bidx * A.p_max + rd) * NW + wave;

@@ -121,6 +121,10 @@ int cslam_pool_profile_begin(cslam_pool_t* pool, int max_launches);
 /* same, bracketing only every `every`-th launch (an event pair costs ~8 us of stream time). */
 int cslam_pool_profile_begin_sampled(cslam_pool_t* pool, int max_samples, int every);
 int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launches);
+/* Measurement knobs (CSLAM_* environment variables) are read once per process; after this
+ * call every knob re-reads its variable at its next use.  For tests and A/B tools, not for the node. */
+int cslam_knobs_reload(void);
+
 /* Name (static string) of the dot-product kernel variant the last search launched, e.g.
  * "k_scan_dma<NS=8,NW=4,NST=2,nt>": what the roofline line of bench.py is about. */
 const char* cslam_pool_scan_kernel(const cslam_pool_t* pool);

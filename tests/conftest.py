@@ -10,9 +10,8 @@ if os.path.join(ROOT, "tools") not in sys.path:     # workload builders shared w
     sys.path.insert(1, os.path.join(ROOT, "tools"))
 
 
-# the library re-reads its measurement knobs (CSLAM_TOPK_WAVES, CSLAM_MQ_TAIL, ...) at every launch
-# instead of once per process, so that a test can compare two settings in one process
-os.environ.setdefault("CSLAM_KNOBS_LIVE", "1")
+# The suite runs on the production path: measurement knobs (CSLAM_TOPK_WAVES, CSLAM_MQ_TAIL, ...) are read
+# once and cached.  A test that compares two settings asks for the `knobs` fixture below.
 
 
 def pytest_configure(config):
@@ -34,3 +33,20 @@ def gpu():
     lib = _lib.load()
     assert lib.cslam_device_count() > 0, "no HIP device visible on a -m gpu run"
     return lib
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    """`knobs.set("CSLAM_TOPK_WAVES", "0")`: change a measurement knob for the rest of THIS test; the
+    library re-reads its knobs now and again when the environment is restored (cslam_knobs_reload)."""
+    from cslam_amd import _lib
+    lib = _lib.load()
+
+    class Knobs(object):
+        def set(self, name, value):
+            monkeypatch.setenv(name, str(value))
+            lib.cslam_knobs_reload()
+
+    yield Knobs()
+    monkeypatch.undo()
+    lib.cslam_knobs_reload()

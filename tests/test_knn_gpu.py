@@ -339,7 +339,7 @@ def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
     (40000, 768, 16, 3),
     (17000, 4096, 7, 10),     # cfg2's row shape
 ])
-def test_fused_top_k_select_matches_oracle(gpu, monkeypatch, n, d, m, k):
+def test_fused_top_k_select_matches_oracle(gpu, knobs, n, d, m, k):
     """search with 2 <= k <= 32 and <= 16 queries: k_scan_dma<best+dots> + k_topk_from_waves (the rows
     of the k best waves only) against the C oracle bit for bit, and against the two-level select
     over every row (CSLAM_TOPK_WAVES=0).  Ties (duplicated rows, a zero query) keep the lowest row
@@ -384,7 +384,7 @@ def test_fused_top_k_select_matches_oracle(gpu, monkeypatch, n, d, m, k):
             assert np.all(idx.cpu().numpy()[:, wk:] == -1)
     mt.close()
     # the two-level select over every row gives the same bytes
-    monkeypatch.setenv("CSLAM_TOPK_WAVES", "0")
+    knobs.set("CSLAM_TOPK_WAVES", "0")
     mt = _pool(gpu, X, dim=d, capacity_hint=n)
     rows2, sims2 = mt.search_batch(Q, k)
     assert "best+dots" not in gpu.cslam_pool_scan_kernel(mt.handle).decode()
@@ -693,11 +693,11 @@ def test_search_best_split_equals_two_range_searches(gpu, n, d, m, split):
     (6000, 1792, 5, 1),        # 7 slices = 4 chunks, the last a single slice; two strips per block
     (7000, 8192, 2, 1),        # 16 chunks: 438 strips would need two strips = 32 partials per block: k_scan_dma
 ])
-def test_small_pool_k_split_scan_is_bit_identical(gpu, monkeypatch, n, d, m, k):
+def test_small_pool_k_split_scan_is_bit_identical(gpu, knobs, n, d, m, k):
     """k_scan_dma_ks (pools of up to three strips per CU, descriptors of >= 4 chunks): the waves of
     a block split the chunks of the block's strips evenly and wave s folds the chunk partials of
     strip s in order — bit-identical to the oracle's sequential fold."""
-    monkeypatch.setenv("CSLAM_SCAN_KSPLIT_STRIPS", "3")   # default 1: more strips per block measured slower
+    knobs.set("CSLAM_SCAN_KSPLIT_STRIPS", "3")   # default 1: more strips per block measured slower
     rs = np.random.RandomState(n + d + m + k)
     X = (rs.rand(n, d).astype(np.float32) - 0.3)
     Q = rs.rand(m, d).astype(np.float32) - 0.3
