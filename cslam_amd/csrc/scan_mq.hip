@@ -75,6 +75,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     // ... and behind the last X piece of that stage's refill (k-block kLastX; B slots follow the X slots)
     constexpr int kLastX = (NP + PPK - 1) / PPK - 1;
     constexpr int kBAfterX = (NBP / NB) * (NB - kLastX) + ((NBP % NB) > kLastX ? (NBP % NB) - kLastX : 0);
+    // chain of k-block kLastX behind which the issue cursor advances: the first one without a piece of its own
+    constexpr int kAdvanceT = PPK < T ? PPK : T - 1;
     constexpr bool PF = NW == 4;          // B fragments of the next k-block prefetched into a second register set
     static_assert(NP == NB && NB >= 4 && (NW == 4 || NW == 8), "geometry");
     static_assert((T - PPK) * NB >= NBPX, "every B piece needs a slot behind a chain t >= PPK of the first stage");
@@ -387,6 +389,14 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                                 issue_piece(PPK * i + t, slot);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
+                            // The last piece of the refill is out: the issue cursor moves on HERE, between two
+                            // chains, where its ~10 scalar instructions and two branches run in the shadow of
+                            // the MFMA in flight - behind the stage's last MFMA (round 3) they were ~150 clocks
+                            // of idle matrix pipe per stage, with one wave per SIMD and nobody to fill them.
+                            if (i == kLastX && t == kAdvanceT) {
+                                i_advance();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             // ... and, in the step's first stage, the next slice's B pieces behind the others
                             if (s == 0 && t >= PPK && i + NB * (t - PPK) < NBPX) {
                                 issue_b_piece(i + NB * (t - PPK), kc_nx, bb ^ 1);
@@ -405,7 +415,6 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     CSLAM_MQ_HOOK_STAGE_END
                     issued += NP;
                     if (s == 0) mark_b = issued;   // an upper bound of the last B piece's position: a longer wait at worst
-                    i_advance();
 #pragma unroll
                     for (int t = 0; t < T; ++t) asm volatile("" : "+a"(acc[s][t]));
                     if (__builtin_expect(fold, 0)) {
@@ -666,6 +675,10 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
     // no running totals, so NS strips x T tiles of accumulators fit 256 registers per wave
     if (mode == kMqModePart && waves == 8 && kw == 64 && tiles >= 2 && tiles <= 5 && a.dp % 64 == 0 && a.n > 0 &&
         a.n_blocks >= 1) {
+        static const int ns_env = getenv("CSLAM_MQ_PART_NS") ? atoi(getenv("CSLAM_MQ_PART_NS")) : 0;   // A/B: strips per panel
+        if (tiles == 5 && ns_env == 3) return launch_one<5, 64, 3, 3, 0, MODE_PART, 8>(a, st);
+        if (tiles == 5 && ns_env == 2) return launch_one<5, 64, 3, 2, 0, MODE_PART, 8>(a, st);
+        if (tiles == 5 && ns_env == 4) return launch_one<5, 64, 3, 4, 0, MODE_PART, 8>(a, st);
         switch (tiles) {
             case 2: return launch_one<2, 64, 3, 8, 0, MODE_PART, 8>(a, st);
             case 3: return launch_one<3, 64, 3, 8, 0, MODE_PART, 8>(a, st);
