@@ -462,7 +462,8 @@ def main():
     # summarised in profiles/r0X_scan_pmc.json; it is only quoted when that summary is about
     # the kernel variant and the shape that ran here - `traffic_source` says where it came from
     traffic, traffic_source = None, None
-    for name in ("r03_scan_pmc.json", "r02_scan_pmc.json"):
+    mfma_busy = None
+    for name in ("r04_scan_pmc.json", "r04_mq_pmc.json", "r03_scan_pmc.json", "r02_scan_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue
@@ -470,6 +471,7 @@ def main():
             rec = json.load(open(pmc))
             if rec.get("kernel") == scan_kernel and rec.get("keyframes") == N and rec.get("dim") == D:
                 traffic = rec.get("hbm_bytes_per_launch")
+                mfma_busy = rec.get("MfmaUtil_median")
                 traffic_source = ("profiles/" + name + " (separate rocprofv3 --pmc passes of this command, "
                                   "not measured in this run)")
                 break
@@ -500,6 +502,8 @@ def main():
                          "frac": tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
                          "hbm_gbs": achieved})
         roofline.pop("frac_of_measured_copy_peak", None)
+        if mfma_busy is not None:      # matrix-pipe busy fraction of the scan launch, same PMC summary
+            roofline["mfma_busy"] = mfma_busy
     result = {
         "metric": METRIC,
         "value": value,
