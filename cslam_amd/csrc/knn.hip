@@ -540,7 +540,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
     // landed, 2.5-3.5 more until the first stage has, then 66 us of streaming,
     // profiles/r03_dma_probe_clock.txt.  With the stage issue BETWEEN the asm loads and their wait it
     // bought 1 us of 78 (profiles/r03_size_sweep_early.txt) and faulted on its first small pool: the
-    // window let the compiler recycle registers the loads still owed.
+    // window let the compiler recycle registers the loads still owed ("The inline-asm load hazard").
     // With the stages issued in front of the asm loads - no window - it is safe (121 tests) and buys
     // nothing (profiles/r03_size_sweep_early2.txt: 77.1-78.7 vs 75.8-79.2 us): not kept.)
 #pragma unroll

@@ -1,7 +1,7 @@
 """Static check of the built device assembly (cslam_amd/csrc/build/*.s, kept by `make`): no instruction
 touches a register that an in-flight inline-asm load still owes - the cause of the GPU memory faults
 (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) of experimental scan variants in rounds 2 and 3 and of a
-stale-copy build in round 4; see tools/check_asm_load_hazard.py and DESIGN.md section 5, item 10.
+stale-copy build in round 4; see tools/check_asm_load_hazard.py and DESIGN.md section 5, "The inline-asm load hazard".
 `make` itself runs the check and fails on a finding; this test keeps the checker honest (its
 self-tests) and fails - not skips - when the library was built without the assembly being kept."""
 import glob

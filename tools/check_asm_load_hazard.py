@@ -1,7 +1,7 @@
 """Static check of the device assembly, run by `make` on every build: no instruction may touch a
 register that an in-flight INLINE-ASM load still owes.
 
-Why: to the compiler the registers an inline-asm load writes are
+Why ("The inline-asm load hazard"): to the compiler the registers an inline-asm load writes are
 defined at the asm statement.  Between the load and the wait that covers it hipcc is free to copy
 them (it then keeps STALE data: a silently wrong query fragment), to spill them, or to hand the
 registers to something else (the load then lands in somebody's address pair: the GPU memory faults
