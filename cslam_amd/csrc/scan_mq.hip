@@ -61,25 +61,22 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     constexpr int NBP = T * NP / NW;      // B pieces per wave and slice (at least: wave w takes pieces w, w + NW, ...)
     constexpr int NBPX = (T * NP + NW - 1) / NW;
     constexpr int RV = MODE == MODE_BEST ? 2 : 0;   // row-norm loads per step
-    // The refill of a slot (stage j + NST into stage j's slot) is issued behind the k-blocks of
-    // stage j, PPK pieces per k-block; in front of k-block WP the NEXT stage must have landed and
-    // the A fragments consumed so far are refreshed from it.  Two stages per wave (T >= 4: the LDS
-    // holds no more beside the query slices): two pieces per k-block and a late wait, so that the
-    // last piece of a stage has (NB/2 + WP) / NB of a stage time to land.
-    constexpr int PPK = NST == 2 ? 2 : 1;
-    constexpr int WP = NB - 2;
-    constexpr int kIssuedAtWP = PPK * WP < NP ? PPK * WP : NP;
-    // B pieces every wave issues in front of k-block WP of a step's first stage (piece x goes behind
-    // chain PPK + x / NB of k-block x % NB): pieces x < NBP with x % NB < WP
-    constexpr int kBBeforeWP = (NBP / NB) * WP + ((NBP % NB) < WP ? (NBP % NB) : WP);
-    // ... and behind the last X piece of that stage's refill (k-block kLastX; B slots follow the X slots)
-    constexpr int kLastX = (NP + PPK - 1) / PPK - 1;
-    constexpr int kBAfterX = (NBP / NB) * (NB - kLastX) + ((NBP % NB) > kLastX ? (NBP % NB) - kLastX : 0);
-    // chain of k-block kLastX behind which the issue cursor advances: the first one without a piece of its own
-    constexpr int kAdvanceT = PPK < T ? PPK : T - 1;
-    constexpr bool PF = NW == 4;          // B fragments of the next k-block prefetched into a second register set
+    // A stage's T x NB k-blocks are walked tile-major in NG groups of HK k-blocks (visit = group x tile:
+    // 4 HK MFMAs in a row on one accumulator); position pos = visit HK + k-block counts them 0 .. T NB - 1.
+    constexpr int HK = NB < 4 ? NB : 4;
+    constexpr int NG = NB / HK;
+    // the refill of a slot (stage j + NST into stage j's slot) is issued one piece behind each of the first
+    // NP positions, the next slice's B pieces (first stage of a step) behind the following NBPX; in front of
+    // position kPosW - the first k-block of the last visit - the NEXT stage must have landed: the A fragments
+    // of the groups that every tile is through with are refreshed from it there, the others behind their
+    // last k-block
+    constexpr int kPosW = (NG * T - 1) * HK;
+    constexpr bool kWrap = (NG * T) % 2 == 0;   // the last visit of a stage prefetches the first of the next
+    // B pieces every wave has certainly issued in front of kPosW (pieces x < NBP at positions NP + x)
+    constexpr int kBBeforeW = kPosW - NP < 0 ? 0 : (kPosW - NP < NBP ? kPosW - NP : NBP);
     static_assert(NP == NB && NB >= 4 && (NW == 4 || NW == 8), "geometry");
-    static_assert((T - PPK) * NB >= NBPX, "every B piece needs a slot behind a chain t >= PPK of the first stage");
+    static_assert(NP + NBPX <= T * NB, "every B piece needs a position behind the X pieces of the first stage");
+    static_assert(NP <= kPosW, "the refill must be out before the wait for the next stage");
     extern __shared__ __attribute__((aligned(16))) char mq_lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             const char* bs = bbuf + bb * T * kStage + rd_off;
             // end of a 512-float chunk / of the row: fold (or, MODE_PART, hand the partial over)
             const bool fold = (((kc_begin + kc + 1) & (kFold - 1)) == 0) || kc_begin + kc + 1 == nkc_all;
-            f32x4 bcur[T];
+            f32x4 bq[2][HK];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (__builtin_expect(s < ns, 1)) {
@@ -328,89 +325,95 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     const int nslot = slot + 1 == NST ? 0 : slot + 1;
                     const char* nx = ring + nslot * kStage + rd_off;
                     CSLAM_MQ_HOOK_STAGE_BEGIN
-                    if (PF && s == 0) {
+                    // ---- the stage's T x NB k-blocks, TILE-MAJOR in groups of HK k-blocks (round 4) ----
+                    // Visit v = (group gi, tile t): HK k-blocks = 4 HK MFMAs in a row on ONE accumulator.
+                    // The matrix pipe forwards the accumulator between back-to-back MFMAs of a chain (32
+                    // clocks each) and pays ~8 clocks at every change of accumulator: round-robin over the
+                    // tiles ran at 38-40 clocks per MFMA, chains of four (round 3: one k-block per tile) at
+                    // 34 isolated / 35.9 in this loop, chains of sixteen leave 0.5 clocks of it
+                    // (tools/mfma_rate2.hip; per-stage stamps in profiles/r04_mq_stage_probe_*.txt).
+                    // Same chains, same order inside each: same bits.  The B fragments of a visit (HK float4)
+                    // sit in bq[v & 1]; those of the next visit - of visit 0 again behind the last: the next
+                    // strip of this step starts with them - are requested behind this visit's first k-block.
+                    // (an odd number of visits per stage - 64-float slices with three or five tiles - would
+                    // hand the next stage its first fragments in the wrong set: every stage then loads them
+                    // itself; those variants run two waves per SIMD or lean on the HBM)
+                    if (s == 0 || !kWrap) {
 #pragma unroll
-                        for (int t = 0; t < T; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage);
+                        for (int ii = 0; ii < HK; ++ii) bq[0][ii] = *reinterpret_cast<const f32x4*>(bs + ii * 64);
                     }
-                    static_for(std::make_integer_sequence<int, NB>{}, [&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        // B fragments of the next k-block (of k-block 0 behind the last: the next
-                        // strip of this step starts with them)
-                        f32x4 bnx[T];
-                        if (!PF) {   // two waves per SIMD: the partner's MFMAs cover this wave's LDS latency
+                    static_for(std::make_integer_sequence<int, NG * T>{}, [&](auto vc) {
+                        constexpr int v = decltype(vc)::value;
+                        constexpr int gi = v / T, t = v % T;
+                        constexpr int vn = v + 1 == NG * T ? 0 : v + 1;      // the visit behind this one
+                        constexpr int gn = vn / T, tn = vn % T;
+                        constexpr int cur = v & 1;
+                        static_for(std::make_integer_sequence<int, HK>{}, [&](auto ic) {
+                            constexpr int ii = decltype(ic)::value;
+                            constexpr int i = gi * HK + ii;                      // k-block of the slice
+                            constexpr int pos = v * HK + ii;                     // position in the stage
+                            f32x4(&bc)[HK] = bq[cur];
+                            f32x4(&bn)[HK] = bq[cur ^ 1];
+                            if (pos == kPosW) {
+                                // The next stage has landed.  Younger than its last piece: the stages behind it
+                                // in the ring, ALL of this stage's refill (issued at positions 0 .. NP - 1), and
+                                // what a step's top and first stage add when they lie in between (row norms, B
+                                // pieces).  Every term is what EVERY wave has certainly issued.
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP + NP +
+                                                                        (s == 0 ? RV + kBBeforeW
+                                                                                : (s <= NST - 2 ? RV + NBP : (s == NST - 1 ? NBP : 0))))
+                                             : "memory");
+                                // A fragments of the groups every tile is through with, from the next stage
 #pragma unroll
-                            for (int t = 0; t < T; ++t)
-                                bcur[t] = *reinterpret_cast<const f32x4*>(bs + t * kStage + i * 64);
-                        }
-                        if (i == WP) {
-                            // The next stage has landed.  Younger than its last piece: the stages
-                            // behind it in the ring, this stage's refill so far, and what a step's top
-                            // and first stage add (row norms, B pieces) when they lie in between.  Every
-                            // term is what EVERY wave has certainly issued: fewer strips per step only
-                            // make the count an under-estimate, i.e. a longer wait - but an
-                            // under-estimate that reaches into the pieces just requested is a stall of a
-                            // whole memory round trip, so the terms are exact for full steps.
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP + kIssuedAtWP +
-                                                                    (s == 0 ? RV + kBBeforeWP
-                                                                            : (s <= NST - 2 ? RV + NBP : (s == NST - 1 ? kBAfterX : 0))))
-                                         : "memory");
-#pragma unroll
-                            for (int i2 = 0; i2 < WP; ++i2)
-                                a[i2] = *reinterpret_cast<const f32x4*>(nx + i2 * 64);
-                        }
-                        // Order of the k-block, pinned by scheduling barriers: the LDS reads first, then
-                        // ONE TILE AFTER THE OTHER - four MFMAs in a row on the same accumulator.  The
-                        // matrix pipe forwards the accumulator between back-to-back MFMAs of one chain
-                        // (32 clocks each); every change of accumulator costs ~8 clocks more: round-robin
-                        // over the tiles, which is what the compiler's scheduler makes of independent
-                        // chains, ran at 40 clocks per MFMA (tools/mfma_rate2.hip,
-                        // profiles/r03_mfma_rate2.txt: 38.1 round-robin, 34.1 in runs of four, one wave
-                        // per SIMD).  Same chains, same order inside each: same bits.
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int t = 0; t < T; ++t) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[s][t] = CSLAM_MQ_MFMA(a[i][j], bcur[t][j], acc[s][t]);
+                                for (int i2 = 0; i2 < (NG - 1) * HK; ++i2)
+                                    a[i2] = *reinterpret_cast<const f32x4*>(nx + i2 * 64);
+                            }
+                            // The four MFMAs of the k-block depend on each other through the accumulator: the
+                            // wave cannot issue the next one for ~32 clocks - and in those clocks it can issue
+                            // anything ELSE.  Everything a k-block has to do besides (next visit's B fragments, a
+                            // DMA piece with its address arithmetic, the issue cursor, the A refresh) is therefore
+                            // placed BETWEEN its MFMAs, one item per gap; behind the fourth MFMA the same work
+                            // (round 3, and the compiler left to itself) holds up the first MFMA of the next chain.
                             __builtin_amdgcn_sched_barrier(0);
-                            if (PF && t == 0) {
-                                // The next k-block's B fragments, requested BEHIND the first chain: hipcc
-                                // waits lgkmcnt(0) in front of a k-block whenever an LDS-DMA was issued
-                                // since the last wait (it cannot count LDS reads past one), so reads
-                                // requested in front of that wait would be waited for on the spot -
-                                // ~120 clocks of LDS latency per k-block, 40 clocks per MFMA instead of 34.
+                            acc[s][t] = CSLAM_MQ_MFMA(a[i][0], bc[ii][0], acc[s][t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (ii == 0 && (kWrap || v + 1 < NG * T)) {
+                                // next visit's B fragments (hipcc waits lgkmcnt(0) in front of a chain whenever an
+                                // LDS-DMA was issued since the last wait: requested here they have the rest of
+                                // the visit to land)
 #pragma unroll
-                                for (int t2 = 0; t2 < T; ++t2)
-                                    bnx[t2] = *reinterpret_cast<const f32x4*>(bs + t2 * kStage + (i + 1 < NB ? i + 1 : 0) * 64);
+                                for (int i2 = 0; i2 < HK; ++i2)
+                                    bn[i2] = *reinterpret_cast<const f32x4*>(bs + tn * kStage + (gn * HK + i2) * 64);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                            // the refill's DMA issues between the first chains of the k-block
-                            if (CSLAM_MQ_REFILL && t < PPK && PPK * i + t < NP) {
-                                issue_piece(PPK * i + t, slot);
+                            acc[s][t] = CSLAM_MQ_MFMA(a[i][1], bc[ii][1], acc[s][t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // the refill of this stage's slot: one piece in each of the first NP k-blocks
+                            if (CSLAM_MQ_REFILL && pos < NP) {
+                                issue_piece(pos, slot);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                            // The last piece of the refill is out: the issue cursor moves on HERE, between two
-                            // chains, where its ~10 scalar instructions and two branches run in the shadow of
-                            // the MFMA in flight - behind the stage's last MFMA (round 3) they were ~150 clocks
-                            // of idle matrix pipe per stage, with one wave per SIMD and nobody to fill them.
-                            if (i == kLastX && t == kAdvanceT) {
+                            // the last piece is out: the issue cursor moves on
+                            if (pos == NP) {
                                 i_advance();
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                            // ... and, in the step's first stage, the next slice's B pieces behind the others
-                            if (s == 0 && t >= PPK && i + NB * (t - PPK) < NBPX) {
-                                issue_b_piece(i + NB * (t - PPK), kc_nx, bb ^ 1);
+                            // in the step's first stage, the next slice's B pieces behind the X pieces
+                            if (s == 0 && pos >= NP && pos - NP < NBPX) {
+                                issue_b_piece(pos - NP, kc_nx, bb ^ 1);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                        }
-                        if (i >= WP) {
-                            a[i] = *reinterpret_cast<const f32x4*>(nx + i * 64);
+                            acc[s][t] = CSLAM_MQ_MFMA(a[i][2], bc[ii][2], acc[s][t]);
                             __builtin_amdgcn_sched_barrier(0);
-                        }
-                        if (PF) {
-#pragma unroll
-                            for (int t = 0; t < T; ++t) bcur[t] = bnx[t];
-                        }
+                            acc[s][t] = CSLAM_MQ_MFMA(a[i][3], bc[ii][3], acc[s][t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // the last visit of a k-block: its A fragment comes from the next stage (behind the
+                            // last MFMA that reads it; the next chain's first MFMA covers the read's issue)
+                            if (v == NG * T - 1) {
+                                a[i] = *reinterpret_cast<const f32x4*>(nx + i * 64);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
                     });
                     CSLAM_MQ_HOOK_STAGE_END
                     issued += NP;
