@@ -158,16 +158,26 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     };
     if (J > 0) i_panel();
     // piece pp of the stage under the issue cursor -> slot `sl`; rows past the panel's end repeat
-    // its last row (clamped: never an address outside the window, results never looked at)
+    // its last row (clamped: never an address outside the window, results never looked at).
+    // The byte offsets of a FULL strip's pieces are loop invariants, kept in NP registers (made opaque so that
+    // they are not re-derived at every issue); the clamp is ONE v_min against the offset of the panel's last row
+    // (i_climit, refreshed when the cursor moves: min(rel, last) xs + seg = min(rel xs + seg, last xs + seg)).
+    // A piece then costs a v_min, an M0 write and the DMA instruction - round 3 paid a v_min and a 64-bit v_mad
+    // per piece, ~20 clocks that no MFMA shadow covers (an LDS-DMA issue already costs ~35, tools/mfma_mix_probe.hip).
+    uint32_t full_off[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        full_off[pp] = (uint32_t)(R * pp + sub) * xs_b + (uint32_t)seg * 16u;
+        asm volatile("" : "+v"(full_off[pp]));
+    }
+    uint32_t i_climit = (uint32_t)i_last * xs_b + (uint32_t)seg * 16u;
     auto issue_piece = [&](int pp, int sl) {
-        int rel = R * pp + sub;
-        rel = rel < i_last ? rel : i_last;
-        const uint32_t off = (uint32_t)rel * xs_b + (uint32_t)seg * 16u;
+        const uint32_t off = full_off[pp] < i_climit ? full_off[pp] : i_climit;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(i_base + off),
                                          (__attribute__((address_space(3))) void*)(ring + sl * kStage + pp * kPiece),
                                          16, 0, AUX);
     };
-    auto i_advance = [&]() {
+    auto i_advance_cursor = [&]() {
         // (the likely path first: every taken branch between two stages costs the wave an instruction
         // buffer refill with nothing on the matrix pipe)
         if (__builtin_expect(i_left <= 1, 0)) {   // nothing behind the last stage: the cursor stays (dummy refills)
@@ -191,6 +201,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
         ++i_rd;
         i_panel();
     };
+    auto i_advance = [&]() {
+        i_advance_cursor();
+        i_climit = (uint32_t)i_last * xs_b + (uint32_t)seg * 16u;   // offset of the last row the next stage may touch
+    };
     // this wave's share of the B pieces of slice kc -> buffer bb: pieces wave, wave + NW, ... of the
     // slice's T NP (piece pi = tile pi / NP, piece pi % NP of the tile)
     // B pieces: piece pi = wave + NW x of a slice holds the query rows R pi .. R pi + R - 1, so its source is
@@ -202,21 +216,23 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     const uint32_t b_lane_off = (uint32_t)(sub * A.dp + seg * 4) * 4u;
     const uint32_t b_stride = (uint32_t)(R * NW * A.dp) * 4u;
     const char* const b_wave = reinterpret_cast<const char*>(A.Q + (int64_t)(R * wave) * A.dp + (int64_t)kc_begin * KW);
-    uint32_t b_lo = 0, b_hi = 0;   // scalar pair: source of this wave's piece 0 of the slice being requested
+    const char* b_cur = b_wave;   // scalar pair: source of this wave's piece 0 of the slice being requested
     auto b_slice = [&](int kc) {
-        const uint64_t v = reinterpret_cast<uint64_t>(b_wave + (int64_t)kc * (KW * 4));
-        b_lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-        b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        asm volatile("" : "+s"(b_lo), "+s"(b_hi));
+        b_cur = b_wave + (int64_t)kc * (KW * 4);
+        asm volatile("" : "+s"(b_cur));   // opaque: no per-piece address is derived from the loop counter
     };
     auto issue_b_piece = [&](int x, int kc, int bb) {
         const int pi = wave + NW * x;
-        if (pi < T * NP) {   // wave-uniform
-            const int t = pi / NP, pp = pi % NP;
-            const char* ub = reinterpret_cast<const char*>(((uint64_t)b_hi << 32) | b_lo) + (uint32_t)x * b_stride;
+        // (compile-time true when the T NP pieces of a slice divide evenly over the waves: no branch then)
+        if ((T * NP) % NW == 0 || pi < T * NP) {   // wave-uniform
+            // the lane offset enters LAST and opaque: scalar base + 32-bit VGPR offset is an addressing mode of
+            // the DMA instruction; a 64-bit per-lane address costs a v_lshl_add_u64 in front of every piece
+            uint32_t lo = b_lane_off;
+            asm volatile("" : "+v"(lo));
+            const char* ub = b_cur + (uint32_t)x * b_stride;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(ub + b_lane_off),
-                (__attribute__((address_space(3))) void*)(bbuf + (bb * T + t) * kStage + pp * kPiece), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(ub + lo),
+                (__attribute__((address_space(3))) void*)(bbuf + (bb * T * NP + pi) * kPiece), 16, 0, 0);
             ++issued;
         }
     };
