@@ -275,21 +275,33 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     int slot = 0;      // ring slot of the stage the consumer is at
     int gstep = 0;
     CSLAM_MQ_HOOK_KERNEL_BEGIN
+    // both accumulator sets live in AccVGPRs across a panel (left to itself hipcc parks them in architectural
+    // VGPRs between a strip's stages - 8 NS T of them - and spills)
+    f32x4 acc[NS][T], tot[NS][T];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(acc[s][t]));
+        }
     for (int rd = 0; rd < P; ++rd) {
         const int rows = panel_rows(rd);
         const int64_t lo = panel_lo(NW * rd + wave);
         const int ns = (rows + 15) >> 4;
-        f32x4 acc[NS][T], tot[NS][T];
+        // the running totals restart with every panel (K-split mode has none: its chunk partials leave at
+        // every fold); the chain accumulators were zeroed once in front of the round loop and every round
+        // ends on a fold, which leaves them zero again - 8 NS T v_accvgpr_write per round less
+        if (MODE != MODE_PART) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                // both live in AccVGPRs across the panel (left to itself hipcc parks them in
-                // architectural VGPRs between a strip's stages - 8 NS T of them - and spills)
-                asm volatile("" : "+a"(acc[s][t]), "+a"(tot[s][t]));
-            }
+                for (int t = 0; t < T; ++t) {
+                    tot[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(tot[s][t]));
+                }
+        }
         for (int kc = 0; kc < nkc; ++kc, ++gstep) {
             const int bb = gstep & 1;
             // my B pieces of this slice have landed ... and so have everybody's; everybody is also
