@@ -2274,7 +2274,9 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         b.p_max = 1;
         b.part = p->part.as<f32x4>();
         b.part_ks = g.tail_ks;
-        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.part_kw, g.part_waves, kMqModePart, false, st));
+        static Knob k_part_nt{"CSLAM_MQ_PART_NT", 1};   // A/B: non-temporal pool reads in the all-K-split launch
+        CSLAM_TRY(launch_scan_mq(b, g.tiles, g.part_kw, g.part_waves, kMqModePart,
+                                 g.n_main == 0 && g.nt && knob(k_part_nt) != 0, st));
         CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * g.waves, st));
     }
     if (prof) {

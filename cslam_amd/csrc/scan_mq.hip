@@ -710,6 +710,16 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
         if (tiles == 5 && ns_env == 3) return launch_one<5, 64, 3, 3, 0, MODE_PART, 8>(a, st);
         if (tiles == 5 && ns_env == 2) return launch_one<5, 64, 3, 2, 0, MODE_PART, 8>(a, st);
         if (tiles == 5 && ns_env == 4) return launch_one<5, 64, 3, 4, 0, MODE_PART, 8>(a, st);
+        // (nt: the pool rows are read once and must not push the chunk partials, which k_mq_combine reads
+        // right behind this launch, out of the Infinity Cache)
+        if (nt) {
+            switch (tiles) {
+                case 2: return launch_one<2, 64, 3, 8, 2, MODE_PART, 8>(a, st);
+                case 3: return launch_one<3, 64, 3, 8, 2, MODE_PART, 8>(a, st);
+                case 4: return launch_one<4, 64, 3, 6, 2, MODE_PART, 8>(a, st);
+                default: return launch_one<5, 64, 3, 6, 2, MODE_PART, 8>(a, st);
+            }
+        }
         switch (tiles) {
             case 2: return launch_one<2, 64, 3, 8, 0, MODE_PART, 8>(a, st);
             case 3: return launch_one<3, 64, 3, 8, 0, MODE_PART, 8>(a, st);
