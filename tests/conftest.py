@@ -43,8 +43,20 @@ def knobs(monkeypatch):
     lib = _lib.load()
 
     class Knobs(object):
+        touched = set()
+
         def set(self, name, value):
             monkeypatch.setenv(name, str(value))
+            self.touched.add(name)
+            lib.cslam_knobs_reload()
+
+        def only(self, env):
+            """Exactly these knobs (of the ones this fixture has touched) are set, the others back at their defaults."""
+            for name in list(self.touched):
+                monkeypatch.delenv(name, raising=False)
+            for name, value in env.items():
+                monkeypatch.setenv(name, str(value))
+                self.touched.add(name)
             lib.cslam_knobs_reload()
 
     yield Knobs()
