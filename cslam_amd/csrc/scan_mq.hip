@@ -13,14 +13,17 @@
 //     counted vmcnt - exactly the X side of k_scan_dma;
 //   * the query block is SHARED: the KW-float slice of all 16 T staged queries sits in LDS (double
 //     buffered, moved by LDS-DMA too, every wave a quarter of the pieces), one raw s_barrier per
-//     slice step.  B fragments go LDS -> VGPR per k-block, so they cost 4 T registers instead of the
-//     128 T of k_scan_dma's register-resident slice - that is what makes T > 1 fit;
+//     slice step.  B fragments go LDS -> VGPR per visit (one tile x HK <= 4 k-blocks, prefetched a
+//     visit ahead), so they cost 2 x 4 HK registers instead of the 128 T of k_scan_dma's
+//     register-resident slice - that is what makes T > 1 fit;
 //   * work order is slice-major inside the panel (the step = one slice for all strips of all four
 //     waves), accumulators acc/tot[NS][T] stay in registers (AccVGPRs) for the whole panel;
-//   * the A fragments of a stage (NB float4 per lane) are refreshed IN PLACE: once k-block i of
-//     stage j is multiplied, a[i] is re-read from stage j+1's slot - no second register set, no
-//     exposed LDS latency between stages; stage j+NST is issued into stage j's slot in pieces
-//     between the k-blocks (a burst of DMA issues keeps the matrix pipe idle).
+//   * the stage body is tile-major: visits (k-block group, tile), HK MFMAs in a row on one
+//     accumulator.  The A fragments of a stage (NB float4 per lane) are refreshed IN PLACE in the
+//     stage's last visits: once k-block i of stage j is multiplied for the last tile, a[i] is
+//     re-read from stage j+1's slot - no second register set, no exposed LDS latency between
+//     stages; stage j+NST is issued into stage j's slot in pieces between the MFMAs of the first
+//     visits (a burst of DMA issues keeps the matrix pipe idle).
 // Numerics: per (row, query) the MFMA chain visits k in the canonical order of DESIGN.md §3, T
 // tiles interleave their independent chains, folds every 512 floats -> bit-identical to every
 // other scan (tests/test_knn_gpu.py).
