@@ -727,7 +727,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_dma(const float* __restrict__ 
         }
         // raw dots out: the plain dots mode, or (DOTS_TOO, search with 2 <= k <= 16) next to the
         // per-wave best composites - the k best waves then bound where the k best rows can be and
-        // the select reads the dots of those waves' rows only (k_topk_from_waves)
+        // the select reads the dots of those waves' rows only (k_topk_from_parts)
         if ((!BEST || DOTS_TOO) && r < m_valid) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -1413,30 +1413,78 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_topk_from_waves: exact top-k (2 <= k <= 32) of ONE query per block from what the fused scan left:
-// the best (similarity, row) composite of every wave (cand) and the raw dots of every row.
-//   The k-th best row is at least as good as the k-th best WAVE maximum (k distinct waves hold k
-//   distinct rows that good), and a wave whose maximum is below it holds no row of the top k: the
-//   candidates are the rows of the k best waves - ~k x 112 rows of the 100 000.  Round 2 ran k
+// k_topk_from_parts: exact top-k (2 <= k <= 32) of ONE query per block from what a fused scan left:
+// the best (similarity, row) composite of every PART of the window (cand) and the raw dots of every
+// row.  A part is what one composite covers: a wave's share of the window (k_scan_dma: WaveParts),
+// a panel of the multi-tile scan's main launch or a strip of its K-split launch (k_scan_mq +
+// k_mq_combine: PanelParts).
+//   The k-th best row is at least as good as the k-th best PART maximum (k distinct parts hold k
+//   distinct rows that good), and a part whose maximum is below it holds no row of the top k: the
+//   candidates are the rows of the k best parts - ~k x 112 rows of the 100 000.  Round 2 ran k
 //   block-wide arg-max rounds over every 4096 rows of the pool plus a merge level (14 + 9 us and a
 //   6.4-MB dots read); this is one launch over ~1100 rows, and no serial rounds: selections are
 //   by RANK (composites are unique: #{others greater} is the output position).
-//   A1  every thread takes <= 4 wave maxima; a hardware wave ranks its 64 thread maxima by their
-//       similarity word (64 readlanes) -> the k-th largest is a lower bound of the k-th best
-//       wave maximum; T1 = the best of the four bounds.
-//   A2  wave maxima >= T1 (a few times k of the ~1000) go to an LDS list with their wave number.
-//   A3  rank inside the list: ranks < k are the k best waves, rank k-1 is the bound Tk.
-//   B1  composites of those waves' rows (dot x 1/||x|| x 1/||q||, as every other path; the row
-//       ranges follow from the scan's even split of the window over n_waves); those >= Tk (k of
+//   A1  every thread takes the best of its part maxima (parts tid, tid + 256, ...); a hardware wave
+//       ranks its 64 thread maxima by their similarity word (64 readlanes) -> the k-th largest is a
+//       lower bound of the k-th best part maximum; T1 = the best of the four bounds.
+//   A2  part maxima >= T1 (a few times k of the ~1000) go to an LDS list with their part number.
+//   A3  rank inside the list: ranks < k are the k best parts, rank k-1 is the bound Tk.
+//   B1  composites of those parts' rows (dot x 1/||x|| x 1/||q||, as every other path; the row
+//       ranges follow from the scan's partition of the window, Parts::range); those >= Tk (k of
 //       them at least, rarely many more) go to the list.
 //   B2  rank inside the list = output position.  A list overflow (> 1024 rows at or above the
-//       bound: an all-zero query over waves of > 64 rows) takes k rounds of block arg-max instead.
+//       bound: an all-zero query over parts of > 64 rows - or > 1024 parts at or above T1: the same
+//       query over a window of many strips) takes k rounds of block arg-max instead.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTopkWavesMaxK = 32;   // (the shard's fused intra + inter search asks for block + nb_best_matches <= 26)
-constexpr int kTopkWavesMax = 1024;   // scan waves (= 4 x CUs at most) and list entries
-__global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restrict__ cand, int64_t cand_stride,
-                                                         int n_waves, const float* __restrict__ dots,
-                                                         int64_t dots_stride, const float* __restrict__ rnx,
+constexpr int kTopkWavesMax = 1024;  // list entries (and the parts of WaveParts: 4 x CUs at most)
+constexpr int kTopkPartsMax = 65535; // part numbers are kept in 16 bits
+
+// k_scan_dma: the window's n rows split evenly over n_waves (launch_scan_dma)
+struct WaveParts {
+    int64_t wq, wrem;
+    __device__ void range(int c, int64_t& lo, int& cnt) const {
+        lo = c * wq + (c < wrem ? c : wrem);
+        cnt = (int)(wq + (c < wrem ? 1 : 0));
+    }
+};
+// k_scan_mq: parts [0, n_main_parts) are the panels of the main launch - number
+// (block * p_max + round) * nw + wave, the strips of a block split evenly over its nw x rounds
+// panels (scan_mq.hip, "Rows are dealt out in whole 16-row strips") - and part n_main_parts + s is
+// strip s of the K-split launch's window [n_main, n) (k_mq_combine)
+struct PanelParts {
+    int64_t n_main, n;
+    int n_blocks, p_max, nw, ns, n_main_parts;
+    __device__ void range(int c, int64_t& lo, int& cnt) const {
+        if (c >= n_main_parts) {
+            lo = n_main + ((int64_t)(c - n_main_parts) << 4);
+            const int64_t left = n - lo;
+            cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+            return;
+        }
+        const int wave = c % nw, br = c / nw, rd = br % p_max, bidx = br / p_max;
+        const int64_t S = (n_main + 15) >> 4;
+        const int64_t bq = S / n_blocks, brem = S - bq * n_blocks;
+        const int64_t bs_lo = (int64_t)bidx * bq + (bidx < brem ? bidx : brem);
+        const int bs = (int)(bq + (bidx < brem ? 1 : 0));
+        const int P = (bs + nw * ns - 1) / (nw * ns);
+        lo = 0;
+        cnt = 0;
+        if (bs == 0 || rd >= P) return;
+        const int npan = nw * P, pq = bs / npan, prem = bs - pq * npan;
+        const int q0 = nw * rd + wave, q1 = q0 + 1;
+        lo = (bs_lo + (int64_t)q0 * pq + (q0 < prem ? q0 : prem)) << 4;
+        int64_t hi = (bs_lo + (int64_t)q1 * pq + (q1 < prem ? q1 : prem)) << 4;
+        hi = hi < n_main ? hi : n_main;
+        cnt = hi > lo ? (int)(hi - lo) : 0;
+    }
+};
+
+template <class Parts>
+__global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restrict__ cand, int64_t cand_stride,
+                                                         int n_parts, const Parts parts,
+                                                         const float* __restrict__ dots, int64_t dots_stride,
+                                                         const float* __restrict__ rnx,
                                                          const float* __restrict__ rnq, uint32_t row0, int64_t n,
                                                          int k, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_sim) {
@@ -1450,19 +1498,18 @@ __global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restr
     __shared__ int cnt1, cnt2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
-    const int64_t wq = n / n_waves, wrem = n - wq * n_waves;
+    const uint64_t* cq = cand + q * cand_stride;
     if (tid == 0) {
         cnt1 = 0;
         cnt2 = 0;
         tk_s = 0;
     }
-    // ---- A1: a lower bound of the k-th best wave maximum ------------------------------------
-    uint64_t wm[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wm[e] = e * 256 + tid < n_waves ? cand[q * cand_stride + e * 256 + tid] : 0;
-    uint64_t gm = wm[0];
-#pragma unroll
-    for (int e = 1; e < 4; ++e) gm = wm[e] > gm ? wm[e] : gm;
+    // ---- A1: a lower bound of the k-th best part maximum --------------------------------------
+    uint64_t gm = 0;
+    for (int c = tid; c < n_parts; c += 256) {
+        const uint64_t v = cq[c];
+        gm = v > gm ? v : gm;
+    }
     const uint32_t ghi = (uint32_t)(gm >> 32);   // an empty thread has 0, below every real similarity word
     int above = 0;
 #pragma unroll
@@ -1479,27 +1526,40 @@ __global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restr
     uint32_t t1 = tw[0];
 #pragma unroll
     for (int x = 1; x < 4; ++x) t1 = tw[x] > t1 ? tw[x] : t1;
-    // ---- A2: the wave maxima at or above the bound --------------------------------------------
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (wm[e] != 0 && (uint32_t)(wm[e] >> 32) >= t1) {
+    // ---- A2: the part maxima at or above the bound ---------------------------------------------
+    for (int c = tid; c < n_parts; c += 256) {
+        const uint64_t v = cq[c];
+        if (v != 0 && (uint32_t)(v >> 32) >= t1) {
             const int pos = atomicAdd(&cnt1, 1);
-            lst[pos] = wm[e];
-            lst_w[pos] = (uint16_t)(e * 256 + tid);
+            if (pos < kTopkWavesMax) {
+                lst[pos] = v;
+                lst_w[pos] = (uint16_t)c;
+            }
         }
+    }
     __syncthreads();
     const int s1 = cnt1;
-    const int nwin = s1 < k ? s1 : k;
-    // ---- A3: rank -> the k best waves and the bound Tk ----------------------------------------
-    for (int i = tid; i < s1; i += 256) {
-        const uint64_t c = lst[i];
-        int rank = 0;
-        for (int j = 0; j < s1; ++j) rank += lst[j] > c ? 1 : 0;
-        if (rank < k) {
-            const int64_t w = lst_w[i];
-            w_lo[rank] = w * wq + (w < wrem ? w : wrem);
-            w_cnt[rank] = (int)(wq + (w < wrem ? 1 : 0));
-            if (rank == k - 1) tk_s = c;
+    const bool every_row = s1 > kTopkWavesMax;   // too many parts that good: every row is a candidate
+    const int nwin = every_row ? 1 : (s1 < k ? s1 : k);
+    // ---- A3: rank -> the k best parts and the bound Tk -----------------------------------------
+    if (every_row) {
+        if (tid == 0) {
+            w_lo[0] = 0;
+            w_cnt[0] = (int)n;
+        }
+    } else {
+        for (int i = tid; i < s1; i += 256) {
+            const uint64_t c = lst[i];
+            int rank = 0;
+            for (int j = 0; j < s1; ++j) rank += lst[j] > c ? 1 : 0;
+            if (rank < k) {
+                int64_t lo;
+                int cnt;
+                parts.range((int)lst_w[i], lo, cnt);
+                w_lo[rank] = lo;
+                w_cnt[rank] = cnt;
+                if (rank == k - 1) tk_s = c;
+            }
         }
     }
     __syncthreads();
@@ -1512,47 +1572,51 @@ __global__ __launch_bounds__(256) void k_topk_from_waves(const uint64_t* __restr
     const int total = w_pre[nwin];
     const uint64_t tk = tk_s;
     const float rq = rnq[q];
-    // window-relative row of candidate number idx: the winners hold wq or wq + 1 rows each, so winner
-    // idx / (wq + 1) is at most a step or two short
+    // window-relative row of candidate number idx: the last winner whose first candidate is <= idx
+    // (nwin <= 32: five steps)
     auto row_at = [&](int idx) -> int64_t {
-        int j = (int)(idx / (wq + 1));
-        j = j < nwin - 1 ? j : nwin - 1;
-        while (j + 1 < nwin && idx >= w_pre[j + 1]) ++j;
+        int j = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (j + step < nwin && idx >= w_pre[j + step]) j += step;
         return w_lo[j] + (idx - w_pre[j]);
     };
     auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
         const int64_t row = row_at(idx);
         return make_comp((dots[q * dots_stride + row] * rnx[row]) * rq, row0 + (uint32_t)row);
     };
-    // ---- B1: the rows of those waves at or above Tk --------------------------------------------
-    // (up to eight candidates per thread with all their loads in flight together: one memory round
-    // trip instead of one per candidate)
-    constexpr int kBatch = 8;
-    for (int base = 0; base < total; base += kBatch * 256) {
-        int64_t row[kBatch];
-        float dv[kBatch], rx[kBatch];
+    int s2 = kTopkWavesMax + 1;
+    if (!every_row) {
+        // ---- B1: the rows of those parts at or above Tk ----------------------------------------
+        // (up to eight candidates per thread with all their loads in flight together: one memory round
+        // trip instead of one per candidate)
+        constexpr int kBatch = 8;
+        for (int base = 0; base < total; base += kBatch * 256) {
+            int64_t row[kBatch];
+            float dv[kBatch], rx[kBatch];
 #pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const int idx = base + e * 256 + tid;
-            row[e] = idx < total ? row_at(idx) : -1;
-        }
+            for (int e = 0; e < kBatch; ++e) {
+                const int idx = base + e * 256 + tid;
+                row[e] = idx < total ? row_at(idx) : -1;
+            }
 #pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const int64_t r_ = row[e] >= 0 ? row[e] : 0;
-            dv[e] = dots[q * dots_stride + r_];
-            rx[e] = rnx[r_];
-        }
+            for (int e = 0; e < kBatch; ++e) {
+                const int64_t r_ = row[e] >= 0 ? row[e] : 0;
+                dv[e] = dots[q * dots_stride + r_];
+                rx[e] = rnx[r_];
+            }
 #pragma unroll
-        for (int e = 0; e < kBatch; ++e) {
-            const uint64_t c = row[e] >= 0 ? make_comp((dv[e] * rx[e]) * rq, row0 + (uint32_t)row[e]) : 0;
-            if (row[e] >= 0 && c >= tk) {
-                const int pos = atomicAdd(&cnt2, 1);
-                if (pos < kTopkWavesMax) lst[pos] = c;
+            for (int e = 0; e < kBatch; ++e) {
+                const uint64_t c = row[e] >= 0 ? make_comp((dv[e] * rx[e]) * rq, row0 + (uint32_t)row[e]) : 0;
+                if (row[e] >= 0 && c >= tk) {
+                    const int pos = atomicAdd(&cnt2, 1);
+                    if (pos < kTopkWavesMax) lst[pos] = c;
+                }
             }
         }
+        __syncthreads();
+        s2 = cnt2;
     }
-    __syncthreads();
-    const int s2 = cnt2;
     if (s2 <= kTopkWavesMax) {
         // ---- B2: rank = output position ---------------------------------------------------------
         for (int i = tid; i < s2; i += 256) {
@@ -2618,9 +2682,47 @@ int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
     return CSLAM_OK;
 }
 
-int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k,
-                    int32_t* out_idx, float* out_sim, hipStream_t st, int64_t row_lo = 0,
-                    int64_t row_hi = -1) {
+int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k, int32_t* out_idx,
+                    float* out_sim, hipStream_t st, int64_t row_lo = 0, int64_t row_hi = -1);
+
+// search with 2 <= k <= 32 of 17..~100 queries over the window [v0, v0 + vn): per pass one k_scan_mq
+// launch (or its main + K-split forms) that leaves the best composite of every panel / strip AND the
+// raw dots, then k_topk_from_parts over the rows of the k best parts - instead of the dots pass and
+// two select levels over every row.
+int topk_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k, int32_t* out_idx,
+                 float* out_sim, hipStream_t st) {
+    const int64_t v0 = p->v0, vn = p->vn;
+    const int64_t sims_stride = (vn + 63) / 64 * 64;
+    CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+    CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+    CSLAM_TRY(p->sims.reserve((size_t)16 * mq_max_tiles() * sims_stride * sizeof(float)));
+    for (int q0 = 0, mb = 0; q0 < m; q0 += mb) {
+        mb = mq_pass_queries(m - q0);
+        if (mb <= 16) {   // a last pass of <= 16 queries: the single-tile path of search
+            CSLAM_TRY(search_dev_impl(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, k, out_idx + (int64_t)q0 * k,
+                                      out_sim + (int64_t)q0 * k, st, v0, v0 + vn));
+            continue;
+        }
+        const MqPlan g = mq_plan(p, mb);
+        const int64_t cstride = (g.n_cand + 63) / 64 * 64;
+        if (g.n_cand > kTopkPartsMax) return fail(CSLAM_E_INVALID, "topk_scan_mq: %lld parts", (long long)g.n_cand);
+        CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+        CSLAM_TRY(mq_pass(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, p->rnq.as<float>() + q0,
+                          p->sims.as<float>(), sims_stride, true, p->cand_a.as<uint64_t>(), cstride, -1, nullptr,
+                          g, st));
+        const PanelParts parts{g.n_main,  vn,      g.n_blocks, g.p_max, g.waves, mq_panel_strips(g.tiles, g.waves),
+                               g.n_blocks * g.p_max * g.waves};
+        hipLaunchKernelGGL((k_topk_from_parts<PanelParts>), dim3(mb), dim3(256), 0, st, p->cand_a.as<uint64_t>(),
+                           cstride, (int)g.n_cand, parts, p->sims.as<float>(), sims_stride, p->inv_norm + v0,
+                           p->rnq.as<float>() + q0, (uint32_t)v0, vn, k, out_idx + (int64_t)q0 * k,
+                           out_sim + (int64_t)q0 * k);
+        CSLAM_HIP_TRY(hipGetLastError());
+    }
+    return CSLAM_OK;
+}
+
+int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k, int32_t* out_idx,
+                    float* out_sim, hipStream_t st, int64_t row_lo, int64_t row_hi) {
     if (m <= 0 || k <= 0) return CSLAM_OK;
     if (row_hi < 0 || row_hi > p->n) row_hi = p->n;
     if (row_lo < 0) row_lo = 0;
@@ -2642,21 +2744,26 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     int64_t chunk = m < qc ? m : qc;
     CSLAM_TRY(p->sims.reserve((size_t)chunk * sims_stride * sizeof(float)));
     float* sims = p->sims.as<float>();
-    // <= 16 queries, 2 <= k <= 32 (lcsm.py:69's k = 10 at a handful of queries): the best-match scan
-    // that also leaves the raw dots, then ONE select launch over the rows of the k best waves
-    // instead of two select levels over every row (k_topk_from_waves).  CSLAM_TOPK_WAVES=0 keeps
-    // the two-level select.
+    // 2 <= k <= 32 (lcsm.py:69's k = 10 at a handful of queries; the sharded step's fused intra + inter
+    // search, K = block + nb_best_matches): the best-match scan that also leaves the raw dots, then ONE
+    // select launch over the rows of the k best parts of the window instead of two select levels over
+    // every row (k_topk_from_parts).  CSLAM_TOPK_WAVES=0 keeps the two-level select.
     static Knob k_tw{"CSLAM_TOPK_WAVES", 1};
     if (k >= 2 && k <= kTopkWavesMaxK && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m) &&
         (int64_t)p->cus * 4 <= kTopkWavesMax && knob(k_tw) != 0) {
         int64_t cstride = 0, n_cand = 0;
         CSLAM_TRY(best_scan_candidates(p, q_dev, q_stride, m, -1, &cstride, &n_cand, st, sims, sims_stride));
-        hipLaunchKernelGGL(k_topk_from_waves, dim3(m), dim3(256), 0, st, p->cand_a.as<uint64_t>(), cstride,
-                           (int)n_cand, sims, sims_stride, p->inv_norm + p->v0, p->rnq.as<float>(),
-                           (uint32_t)p->v0, p->vn, k, out_idx, out_sim);
+        const WaveParts parts{p->vn / n_cand, p->vn % n_cand};
+        hipLaunchKernelGGL((k_topk_from_parts<WaveParts>), dim3(m), dim3(256), 0, st, p->cand_a.as<uint64_t>(),
+                           cstride, (int)n_cand, parts, sims, sims_stride, p->inv_norm + p->v0,
+                           p->rnq.as<float>(), (uint32_t)p->v0, p->vn, k, out_idx, out_sim);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
+    // ... and for 17+ queries: k_scan_mq passes that leave one composite per query and panel (or strip of
+    // the K-split launch) beside the dots
+    if (k >= 2 && k <= kTopkWavesMaxK && m > 16 && mq_best_applies(p, m) && knob(k_tw) != 0)
+        return topk_scan_mq(p, q_dev, q_stride, m, k, out_idx, out_sim, st);
     for (int q0 = 0; q0 < m; q0 += (int)qc) {
         int mb = m - q0 < (int)qc ? m - q0 : (int)qc;
         CSLAM_TRY(compute_dots(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, sims, sims_stride,

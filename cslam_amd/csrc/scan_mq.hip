@@ -28,8 +28,9 @@
 // tiles interleave their independent chains, folds every 512 floats -> bit-identical to every
 // other scan (tests/test_knn_gpu.py).
 //
-// MODE_DOTS raw dots out; MODE_BEST (k = 1): one (similarity, row) composite per query and panel
-// (+ the split window of csrc/shard.hip); MODE_PART: the block multiplies only the 512-float
+// MODE_DOTS raw dots out; MODE_BEST: one (similarity, row) composite per query and panel
+// (+ the split window of csrc/shard.hip; + the raw dots when A.dots is given: search with
+// 2 <= k <= 32, whose select then reads the rows of the k best panels only); MODE_PART: the block multiplies only the 512-float
 // chunks [chunk_lo, chunk_hi) of its rows and leaves every chunk's partial in a scratch array -
 // the K-split tail / small-pool pass, folded in chunk order by k_mq_combine (same bits).
 #include <type_traits>
@@ -541,6 +542,18 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                     A.cand[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best;
                     if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best_c;
                 }
+                // search with k > 1 (k_topk_from_parts): the raw dots beside the composites (wave-uniform)
+                if (A.dots != nullptr && 16 * t + er < A.m_valid) {
+                    float* out = A.dots + (int64_t)(16 * t + er) * A.dots_stride + lo + 4 * eg;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (s < ns) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (16 * s + 4 * eg + e < rows) out[16 * s + e] = tot[s][t][e];
+                        }
+                    }
+                }
             }
         } else if (MODE == MODE_DOTS) {
             const int64_t hi = lo + rows;
@@ -641,7 +654,9 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
             A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best;
             if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best_c;
         }
-    } else if (16 * t + r < A.m_valid) {
+    }
+    // raw dots: dots mode, and beside the composites for search with k > 1 (k_topk_from_parts)
+    if ((!BEST || A.dots != nullptr) && 16 * t + r < A.m_valid) {
         const int64_t r0 = lo + 4 * g;
         float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
 #pragma unroll

@@ -447,6 +447,77 @@ def test_dma_scan_matches_oracle(gpu, n, d, m, k):
 
 
 @pytest.mark.parametrize("n,d,m,k", [
+    (25000, 1024, 80, 18),     # all K-split (1563 strips = 1563 parts > the list: the zero query takes every row)
+    (25000, 1024, 80, 26),     # the sharded step's fused search at eight robots: block of 10 + ... <= 26
+    (12000, 1024, 48, 10),     # fewer strips than waves, three tiles
+    (70000, 512, 80, 10),      # main launch + K-split tail: panels of four strips and single strips mixed
+    (100000, 128, 33, 10),     # lcsm.py:69's k at the reference's descriptor length: six strips per panel
+    (300000, 128, 40, 32),     # several rounds per block (p_max > 1), the largest k
+    (20011, 192, 17, 2),       # 64-float slices, two tiles (never all K-split), the smallest k
+    (4100, 640, 64, 5),        # a chunk and a quarter
+    (40, 128, 20, 16),         # three strips in the pool
+    (9, 128, 17, 12),          # k > n: (-1, -inf) tails
+    (9000, 4096, 96, 10),      # two balanced passes of 48
+])
+def test_multi_tile_top_k_from_parts(gpu, knobs, n, d, m, k):
+    """search with 2 <= k <= 32 and 17+ queries (the intra + inter search of the sharded step,
+    loop_closure_sparse_matching.py:78-97 at K = block + nb_best_matches): k_scan_mq leaves the best
+    composite of every panel / K-split strip beside the raw dots and k_topk_from_parts ranks the rows
+    of the k best parts only.  Against the C oracle bit for bit, against the two-level select over
+    every row (CSLAM_TOPK_WAVES=0), through a row window, with ties across parts and a zero query."""
+    import ctypes
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(n + d + k + m)
+    X = (rs.rand(n, d).astype(np.float32) - 0.3)
+    if n > 300:
+        X[n // 2] = X[7]          # duplicates in different parts
+        X[n - 1] = X[7]
+        X[50] = 0.0
+    Q = rs.rand(m, d).astype(np.float32)
+    Q[0] = X[min(7, n - 1)]
+    Q[2] = 0.0                    # every similarity 0: rows 0..k-1 in order
+    Q[m - 1] = X[min(7, n - 1)]
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows, sims = mt.search_batch(Q, k)
+    name = gpu.cslam_pool_scan_kernel(mt.handle).decode()
+    assert name.startswith("k_scan_mq") and "best" in name, name
+    o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+    kk = int(o_cnt[0])
+    np.testing.assert_array_equal(rows[:, :kk], o_idx[:, :kk])
+    assert sims[:, :kk].tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    if n > 300:
+        assert list(rows[0][:3]) == [7, n // 2, n - 1][:min(k, 3)]
+        assert list(rows[m - 1][:3]) == [7, n // 2, n - 1][:min(k, 3)]
+        assert list(rows[2]) == list(range(k))
+    # a row window through the device-pointer API
+    lo, hi = n // 3, n - n // 5
+    if hi - lo >= 1:
+        q = torch.from_numpy(Q).cuda()
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+        sim = torch.empty((m, k), dtype=torch.float32, device="cuda")
+        rc = gpu.cslam_pool_search_range_dev(mt.handle, ctypes.c_void_p(q.data_ptr()), q.stride(0), m, k, lo, hi,
+                                             ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        w_idx, w_sim, w_cnt = oracle_knn.search(X[lo:hi], Q, k)
+        wk = int(w_cnt[0])
+        np.testing.assert_array_equal(idx.cpu().numpy()[:, :wk], w_idx[:, :wk] + lo)
+        assert sim.cpu().numpy()[:, :wk].tobytes() == w_sim[:, :wk].astype(np.float32).tobytes()
+        if wk < k:
+            assert np.all(idx.cpu().numpy()[:, wk:] == -1)
+    mt.close()
+    # the dots pass + two-level select over every row gives the same bytes
+    knobs.set("CSLAM_TOPK_WAVES", "0")
+    mt = _pool(gpu, X, dim=d, capacity_hint=n)
+    rows2, sims2 = mt.search_batch(Q, k)
+    assert "best" not in gpu.cslam_pool_scan_kernel(mt.handle).decode()
+    np.testing.assert_array_equal(rows2, rows)
+    assert sims2.tobytes() == sims.tobytes()
+    mt.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
     # 4096-d (cfg2 / cfg4 row shape): every tile count, ragged query counts, k = 1 (fused arg-max
     # epilogue) and k > 1 (raw dots + select)
     (9000, 4096, 17, 1), (9000, 4096, 33, 1), (9000, 4096, 48, 1), (9000, 4096, 64, 1),
