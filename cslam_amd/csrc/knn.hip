@@ -19,6 +19,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -109,6 +110,39 @@ __global__ __launch_bounds__(256) void k_append_rows(const float* __restrict__ s
     if (lane == 0) inv_norm[first + w] = inv_norm_from_sumsq(ss);
 }
 
+// 1 / max(||q||, 1e-8) of one query row (dim floats at s, taken as zero padded to dp) by ONE wave:
+// ||q||^2 in wave64 order straight from the source values (loads batched 8 deep: the chain order is
+// per lane, not per load).  Result in every lane.
+__device__ inline float query_inv_norm_wave64(const float* __restrict__ s, int dim, int dp, int vec_ok, int lane) {
+    float ss = 0.0f;
+    for (int base0 = 4 * lane; base0 < dp; base0 += 256 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = base0 + 256 * u;
+            if (k < dp) {
+                if (vec_ok && k + 3 < dim)
+                    v[u] = *reinterpret_cast<const f32x4*>(s + k);
+                else
+                    v[u] = f32x4{ld_or_zero(s, k, dim), ld_or_zero(s, k + 1, dim),
+                                 ld_or_zero(s, k + 2, dim), ld_or_zero(s, k + 3, dim)};
+            } else {
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // fmaf(0,0,ss) == ss: no-op past the row
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ss = __builtin_fmaf(v[u].x, v[u].x, ss);
+            ss = __builtin_fmaf(v[u].y, v[u].y, ss);
+            ss = __builtin_fmaf(v[u].z, v[u].z, ss);
+            ss = __builtin_fmaf(v[u].w, v[u].w, ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, kWave);
+    return inv_norm_from_sumsq(ss);
+}
+
 // queries → staging [mq_pad][dp] (zero padded, rows >= m are zero) and rnq[mq_pad].
 // One 256-thread block per query row; wave 0 also computes ||q||^2 in wave64 order straight
 // from the source values (loads batched 8 deep: the chain order is per lane, not per load).
@@ -140,34 +174,8 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
         *reinterpret_cast<f32x4*>(d + k) = v;
     }
     if (tid < 64 && blockIdx.y == 0) {
-        const int lane = tid;
-        float ss = 0.0f;
-        for (int base0 = 4 * lane; base0 < dp; base0 += 256 * 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = base0 + 256 * u;
-                if (k < dp) {
-                    if (vec_ok && k + 3 < dim)
-                        v[u] = *reinterpret_cast<const f32x4*>(s + k);
-                    else
-                        v[u] = f32x4{ld_or_zero(s, k, dim), ld_or_zero(s, k + 1, dim),
-                                     ld_or_zero(s, k + 2, dim), ld_or_zero(s, k + 3, dim)};
-                } else {
-                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};  // fmaf(0,0,ss) == ss: no-op past the row
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ss = __builtin_fmaf(v[u].x, v[u].x, ss);
-                ss = __builtin_fmaf(v[u].y, v[u].y, ss);
-                ss = __builtin_fmaf(v[u].z, v[u].z, ss);
-                ss = __builtin_fmaf(v[u].w, v[u].w, ss);
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, kWave);
-        if (lane == 0) rnq[w] = inv_norm_from_sumsq(ss);
+        const float rn = query_inv_norm_wave64(s, dim, dp, vec_ok, tid);
+        if (tid == 0) rnq[w] = rn;
     }
 }
 
@@ -1656,6 +1664,139 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_small_best: search_best of <= 16 queries over a SMALL window (<= 4096 rows) in ONE launch - the
+// per-keyframe call of the reference at its own scale (nns_matching.py:66-78 on a pool of a few
+// hundred 128-d descriptors: BASELINE configs[0]).  The general path is a copy of the queries into
+// HBM + k_stage_queries + a scan + k_best_pair: four dependent operations of 4-8 us each around
+// ~2 us of work.  Here the queries are read where the caller left them (device memory, or the pinned
+// bounce buffer of the host-pointer API: no copy), every block restates the stage kernel's 1/||q||,
+// and the final level is an atomic maximum of the composites (order-free) plus a ticket: the last
+// block to finish converts the winners and leaves the scratch zeroed for the next call.
+//   A block owns `spb` strips of 16 rows; its (strip, 512-float chunk) units are dealt over the four
+//   waves; a unit is the MFMA chain of DESIGN.md section 3 from 0 (operands straight from global memory, two
+//   batches of eight k-blocks in flight); chunk partials meet in the LDS and wave s folds strip s's in
+//   chunk order - the arithmetic of every other scan, same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmallBestMaxRows = 4096, kSmallBestMaxChunks = 16, kSmallBestMaxQFloats = 8192;
+constexpr int64_t kSmallBestMaxFloats = (int64_t)6 << 20;
+__global__ __launch_bounds__(256) void k_small_best(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
+                                                    const float* __restrict__ Q, int64_t q_stride, int dim, int m,
+                                                    int vec_ok, const float* __restrict__ rnx, uint32_t row0,
+                                                    int spb, int nchunks, uint64_t* __restrict__ best,
+                                                    uint32_t* __restrict__ ticket, int32_t* __restrict__ out_idx,
+                                                    float* __restrict__ out_sim, uint32_t* __restrict__ done,
+                                                    uint32_t seq) {
+    extern __shared__ f32x4 sb_part[];   // [spb * nchunks][64]
+    __shared__ float rq_s[16];
+    __shared__ int last_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t S = (n + 15) >> 4;
+    const int64_t s_first = (int64_t)blockIdx.x * spb;
+    const int nkb_all = dp >> 4;
+    const float* qrow = Q + (int64_t)r * q_stride;
+    auto b_at = [&](int kb) -> f32x4 {   // B fragment: Q[r][16 kb + 4 g .. + 3], zero past m / dim
+        const int k = 16 * kb + 4 * g;
+        if (r >= m) return f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec_ok && k + 3 < dim) return *reinterpret_cast<const f32x4*>(qrow + k);
+        return f32x4{ld_or_zero(qrow, k, dim), ld_or_zero(qrow, k + 1, dim), ld_or_zero(qrow, k + 2, dim),
+                     ld_or_zero(qrow, k + 3, dim)};
+    };
+    for (int u = wave; u < spb * nchunks; u += 4) {
+        const int s = u / nchunks, c = u - s * nchunks;
+        const int64_t strip = s_first + s;
+        if (strip >= S) break;   // (units are strip-major: nothing behind it either)
+        int64_t row = (strip << 4) + r;
+        row = row < n ? row : n - 1;   // rows past the window repeat its last row; masked below
+        const f32x4* ap = reinterpret_cast<const f32x4*>(X + row * xs + 4 * g);
+        const int kb0 = 32 * c, kb1 = kb0 + 32 < nkb_all ? kb0 + 32 : nkb_all;
+        f32x4 acc{0.f, 0.f, 0.f, 0.f};
+        f32x4 a[2][8], b[2][8];
+        auto load = [&](int set, int kb) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool in = kb + i < kb1;
+                a[set][i] = in ? ap[(int64_t)(kb + i) * 4] : f32x4{0.f, 0.f, 0.f, 0.f};   // fmaf(0, 0, acc) = acc
+                b[set][i] = in ? b_at(kb + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto mul = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[set][i][j], b[set][i][j], acc, 0, 0, 0);
+        };
+        load(0, kb0);
+#pragma unroll 1
+        for (int kb = kb0; kb < kb1; kb += 16) {
+            load(1, kb + 8);
+            mul(0);
+            if (kb + 8 < kb1) {   // wave-uniform (a 128-float row is one batch)
+                load(0, kb + 16);
+                mul(1);
+            }
+        }
+        sb_part[u * 64 + lane] = acc;
+    }
+    // 1 / ||q||: query j by wave (j + 1) % 4 (one query: beside wave 0's unit)
+    for (int j = 0; j < m; ++j)
+        if (((j + 1) & 3) == wave) {
+            const float rn = query_inv_norm_wave64(Q + (int64_t)j * q_stride, dim, dp, vec_ok, lane);
+            if (lane == 0) rq_s[j] = rn;
+        }
+    __syncthreads();
+    for (int s = wave; s < spb; s += 4) {
+        const int64_t strip = s_first + s;
+        if (strip >= S) break;
+        f32x4 tot{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunks; ++c) tot = tot + sb_part[(s * nchunks + c) * 64 + lane];
+        const int64_t lo = strip << 4;
+        const int rows = (int)(n - lo < 16 ? n - lo : 16);
+        const float rq = r < m ? rq_s[r] : 0.0f;
+        uint64_t bst = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rel = 4 * g + e;
+            const int64_t row = lo + rel < n ? lo + rel : n - 1;
+            const float sim = (tot[e] * rnx[row]) * rq;
+            const uint64_t cmp = make_comp(sim, row0 + (uint32_t)(lo + rel));
+            bst = (rel < rows && cmp > bst) ? cmp : bst;
+        }
+        uint64_t o = __shfl_xor(bst, 16, 64);
+        bst = o > bst ? o : bst;
+        o = __shfl_xor(bst, 32, 64);
+        bst = o > bst ? o : bst;
+        if (g == 0 && r < m)
+            __hip_atomic_fetch_max(&best[r], bst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last block to get here sees every block's maxima: every thread's atomics are performed
+    // (fence) before its block takes a ticket
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = t == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (tid < m) {
+        const uint64_t w = __hip_atomic_load(&best[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        out_idx[tid] = comp_row(w);
+        out_sim[tid] = comp_sim(w);
+        __hip_atomic_store(&best[tid], (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (done != nullptr) {
+        // host-pointer API: the results sit in pinned host memory and the host polls `done` for this call's
+        // number instead of paying a stream synchronisation (results first, system-wide, then the number)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // final level of search_best: one block per (query, window) reduces the waves' composites.
 // window 1 (blockIdx.y == 1) exists for the split search only.
 __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ cand_a,
@@ -1691,6 +1832,8 @@ struct cslam_pool {
     float* inv_norm = nullptr;  // [cap]
     hipStream_t stream = nullptr;
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, part;
+    DevBuf small_scratch;              // k_small_best: 16 composites + the ticket, zero between calls
+    uint32_t small_seq = 0;            // call number the host polls for (host-pointer API)
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
     PinBuf pin_rows;                   // pinned ring of cslam_pool_add's small appends
@@ -2682,6 +2825,45 @@ int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
     return CSLAM_OK;
 }
 
+// search_best of a few queries over a small window in ONE launch (k_small_best).  CSLAM_SMALL_BEST=0:
+// the general path (stage + scan + final level) - A/B runs and the tests that compare the two.
+bool small_best_applies(const cslam_pool* p, int m) {
+    static Knob k_small{"CSLAM_SMALL_BEST", 1};
+    const int nchunks = (p->dp + 511) / 512;
+    // (24 MB of rows at most: 4000 x 4096-d is 1.7 us faster on the general path's LDS-DMA K-split scan,
+    // 1000 x 4096-d 5 us slower, profiles/r04_small_best_ab.txt)
+    return knob(k_small) != 0 && m >= 1 && m <= 16 && p->vn >= 1 && p->vn <= kSmallBestMaxRows &&
+           nchunks <= kSmallBestMaxChunks && (int64_t)m * p->dp <= kSmallBestMaxQFloats &&
+           p->vn * p->dp <= kSmallBestMaxFloats;
+}
+// (q may be any device-visible memory: HBM, or pinned host memory read over the host link)
+int small_best(cslam_pool* p, const float* q, int64_t q_stride, int m, int32_t* out_idx, float* out_sim,
+               hipStream_t st, uint32_t* done = nullptr, uint32_t seq = 0) {
+    if (p->small_scratch.p == nullptr) {
+        CSLAM_TRY(p->small_scratch.reserve(256));
+        CSLAM_HIP_TRY(hipMemsetAsync(p->small_scratch.p, 0, 256, st));
+    }
+    const int nchunks = (p->dp + 511) / 512;
+    const int spb = nchunks >= 4 ? 1 : 4 / nchunks;   // four (strip, chunk) units per block at least
+    const int64_t strips = (p->vn + 15) / 16;
+    const unsigned grid = (unsigned)((strips + spb - 1) / spb);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+    const bool prof = prof_take(p);
+    if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
+    hipLaunchKernelGGL(k_small_best, dim3(grid), dim3(256), (size_t)spb * nchunks * 64 * sizeof(f32x4), st,
+                       p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, q, q_stride, p->dim, m, vec_ok,
+                       p->inv_norm + p->v0, (uint32_t)p->v0, spb, nchunks, p->small_scratch.as<uint64_t>(),
+                       reinterpret_cast<uint32_t*>(p->small_scratch.as<uint64_t>() + 16), out_idx, out_sim, done,
+                       seq);
+    CSLAM_HIP_TRY(hipGetLastError());
+    if (prof) {
+        CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
+        p->prof_n++;
+    }
+    p->last_scan_kernel = "k_small_best";
+    return CSLAM_OK;
+}
+
 int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int k, int32_t* out_idx,
                     float* out_sim, hipStream_t st, int64_t row_lo = 0, int64_t row_hi = -1);
 
@@ -2735,6 +2917,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
+    if (k == 1 && small_best_applies(p, m)) return small_best(p, q_dev, q_stride, m, out_idx, out_sim, st);
     if (k == 1 && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m))
         return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
     if (k == 1 && mq_best_applies(p, m))
@@ -2860,6 +3043,7 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_c.release();
     p->comp.release();
     p->part.release();
+    p->small_scratch.release();
     p->h_q.release();
     p->h_idx.release();
     p->h_sim.release();
@@ -3087,12 +3271,50 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
     const bool small = qbytes <= ((size_t)8 << 20) && obytes <= ((size_t)1 << 16);
     if (small) {
         const size_t sim_off = (obytes * sizeof(int32_t) + 63) / 64 * 64;
+        const size_t done_off = (sim_off + obytes * sizeof(float) + 63) / 64 * 64;
         CSLAM_TRY(p->pin_q.reserve(qbytes));
-        CSLAM_TRY(p->pin_out.reserve(sim_off + obytes * sizeof(float)));
+        CSLAM_TRY(p->pin_out.reserve(done_off + 64));
         memcpy(p->pin_q.p, queries, qbytes);
-        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
         int32_t* idx_pin = p->pin_out.as<int32_t>();
         float* sim_pin = reinterpret_cast<float*>(static_cast<char*>(p->pin_out.p) + sim_off);
+        p->v0 = 0;
+        p->vn = p->n;
+        if (k == 1 && small_best_applies(p, n_queries)) {
+            // A small pool's best match - the reference's per-keyframe call at its own scale - is ONE launch
+            // (k_small_best).  Queries of up to 1 KiB are read by the kernel from the pinned buffer itself
+            // (no copy operation in front of the launch; larger ones would cross the host link once per
+            // block), and the host polls a word the kernel writes behind its results instead of paying a
+            // stream synchronisation.  CSLAM_SMALL_BEST_Q=0/1 and CSLAM_SMALL_BEST_POLL=0: A/B.
+            static Knob k_q{"CSLAM_SMALL_BEST_Q", -1};
+            static Knob k_poll{"CSLAM_SMALL_BEST_POLL", 1};
+            const bool from_pin = knob(k_q) < 0 ? qbytes <= 1024 : knob(k_q) != 0;
+            if (!from_pin)
+                CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+            uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(p->pin_out.p) + done_off);
+            const uint32_t seq = ++p->small_seq ? p->small_seq : ++p->small_seq;   // never 0
+            const bool poll = knob(k_poll) != 0;
+            if (poll) __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
+            CSLAM_TRY(small_best(p, from_pin ? p->pin_q.as<float>() : p->h_q.as<float>(), p->dim, n_queries,
+                                 idx_pin, sim_pin, p->stream, poll ? done : nullptr, seq));
+            bool seen = false;
+            if (poll) {
+                // (a kernel that never writes the word - a fault - ends in the synchronisation below, which
+                // reports it)
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int spins = 1; !seen; ++spins) {
+                    seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq;
+                    if (!seen && (spins & 255) == 0 &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                        break;
+                }
+            }
+            if (!seen) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+            memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));
+            memcpy(out_sim, sim_pin, obytes * sizeof(float));
+            p->dev_pending = false;
+            return CSLAM_OK;
+        }
+        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
         CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, idx_pin, sim_pin, p->stream));
         CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
         memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));

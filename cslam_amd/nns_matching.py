@@ -95,6 +95,7 @@ class NearestNeighborsMatching(object):
         self._pool = None
         self._capacity_hint = int(capacity_hint)
         self.data = []  # like the reference until the dimension is known
+        self._one = None  # result buffers of search_best
         if dim is not None:
             self._create(int(dim))
 
@@ -262,8 +263,23 @@ class NearestNeighborsMatching(object):
         (None, None) while the pool has no storage yet."""
         if len(self.data) == 0:
             return None, None
-        items, similarities = self.search(query, 1)
-        return items[0], similarities[0]
+        if self.n == 0:
+            items, similarities = self.search(query, 1)
+            return items[0], similarities[0]
+        # one query, k = 1 - the call the reference makes per keyframe: result buffers and their pointers
+        # are made once per pool (a third of the call's time at the reference's own pool sizes otherwise)
+        one = self._one
+        if one is None:
+            idx, sim, cnt = np.empty(1, np.int32), np.empty(1, np.float32), np.empty(1, np.int32)
+            one = self._one = (idx, sim, _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt))
+        q = query if (type(query) is np.ndarray and query.dtype == np.float32 and query.flags["C_CONTIGUOUS"]) \
+            else _to_numpy_f32(query)
+        if q.size != self.dim:
+            raise ValueError(f"query size {q.size} != pool dim {self.dim}")
+        rc = self._lib.cslam_pool_search(self._pool, q.ctypes.data, 1, 1, one[2], one[3], one[4])
+        if rc != 0:
+            _lib.check(rc)
+        return self.items[int(one[0][0])], one[1][0]
 
     def search_best_batch(self, queries):
         """search_best for every row of `queries`: (items list, sims[M]); empty pool →

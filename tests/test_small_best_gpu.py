@@ -1,0 +1,166 @@
+"""search_best on a SMALL pool in one launch (k_small_best, round 4): the reference's per-keyframe call
+(nns_matching.py:66-78: search(query, 1) on a pool of a few hundred 128-d descriptors, BASELINE
+configs[0]) without the query copy, the stage kernel and the final-level kernel of the general path.
+Bit for bit against the C oracle and against the general path (CSLAM_SMALL_BEST=0); queries from host
+memory, from HBM (aligned, strided, unaligned), through a row window; ties, zero rows, zero queries;
+call after call (the kernel leaves its scratch zeroed for the next one)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import knn as oracle_knn
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(X):
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    m = NearestNeighborsMatching(dim=X.shape[1], capacity_hint=max(1, X.shape[0]))
+    m.add_items(X, list(range(X.shape[0])))
+    return m
+
+
+def _data(n, d, m, seed):
+    rs = np.random.RandomState(seed)
+    X = rs.rand(n, d).astype(np.float32) - 0.3
+    Q = rs.rand(m, d).astype(np.float32) - 0.2
+    if n > 40:
+        X[n - 2] = X[5]            # a tie across strips and blocks resolves to the lower row
+        X[20] = 0.0                # a zero row: similarity 0
+        Q[m - 1] = X[5]
+    if m > 2:
+        Q[1] = 0.0                 # a zero query: every similarity 0, row 0 wins
+    return X, Q
+
+
+SHAPES = [
+    (1000, 128, 1),     # cfg1: one query, 63 strips, four strips per block
+    (1, 128, 1), (15, 128, 2), (16, 128, 1), (17, 128, 3),
+    (4096, 128, 16),    # the largest window, a full query tile
+    (1500, 4096, 1),    # eight chunks per strip: the waves of a block split K (24 MB of rows: the limit)
+    (700, 4096, 2),     # two queries of 4096 floats: the most query floats taken
+    (300, 1000, 4),     # dim padded to 1024: two chunks, two strips per block
+    (333, 1536, 5),     # three chunks: one strip per block, a wave idle
+    (100, 33, 5),       # dim padded to 64
+    (50, 10, 2),        # dim padded to 16 (the LDS-DMA scans do not take such rows)
+    (700, 8192, 1),     # sixteen chunks
+    (999, 200, 7),      # dim % 4 == 0 but rows of 200 floats: 13 k-blocks, a ragged batch
+]
+
+
+@pytest.mark.parametrize("n,d,m", SHAPES)
+def test_small_pool_best_match_in_one_launch(gpu, knobs, n, d, m):
+    torch = pytest.importorskip("torch")
+    X, Q = _data(n, d, m, 7 * n + d + m)
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 1)
+    p = _pool(X)
+    # host-pointer API, twice (scratch reset), then per query like the reference does
+    for _ in range(2):
+        rows, sims = p.search_batch(Q, 1)
+        assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best"
+        np.testing.assert_array_equal(rows, o_idx[:, :1])
+        assert sims.tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
+    for j in range(m):
+        item, sim = p.search_best(Q[j])
+        assert item == int(o_idx[j, 0]) and np.float32(sim).tobytes() == np.float32(o_sim[j, 0]).tobytes()
+    if n > 40:
+        assert rows[m - 1, 0] == 5
+        if m > 2:
+            assert rows[1, 0] == 0 and sims[1, 0] == 0.0
+    # device-pointer API: aligned, strided (row stride d + 4) and unaligned (offset by one float) queries
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    idx = torch.empty((m, 1), dtype=torch.int32, device="cuda")
+    sim = torch.empty((m, 1), dtype=torch.float32, device="cuda")
+    wide = torch.zeros((m, d + 4), dtype=torch.float32, device="cuda")
+    wide[:, :d] = torch.from_numpy(Q)
+    flat = torch.zeros(m * d + 1, dtype=torch.float32, device="cuda")
+    flat[1:] = torch.from_numpy(Q).reshape(-1)
+    for ptr, stride in ((torch.from_numpy(Q).cuda(), d), (wide, d + 4), (flat[1:], d)):
+        idx.fill_(-7)
+        assert gpu.cslam_pool_search_dev(p.handle, ctypes.c_void_p(ptr.data_ptr()), stride, m, 1,
+                                         ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()), st) == 0
+        torch.cuda.synchronize()
+        assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best"
+        np.testing.assert_array_equal(idx.cpu().numpy(), o_idx[:, :1])
+        assert sim.cpu().numpy().tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
+    # a row window
+    lo, hi = n // 3, n - n // 5
+    if hi > lo:
+        q = torch.from_numpy(Q).cuda()
+        assert gpu.cslam_pool_search_range_dev(p.handle, ctypes.c_void_p(q.data_ptr()), d, m, 1, lo, hi,
+                                               ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()), st) == 0
+        torch.cuda.synchronize()
+        w_idx, w_sim, _ = oracle_knn.search(X[lo:hi], Q, 1)
+        np.testing.assert_array_equal(idx.cpu().numpy(), w_idx[:, :1] + lo)
+        assert sim.cpu().numpy().tobytes() == w_sim[:, :1].astype(np.float32).tobytes()
+    # the host-pointer call's variants: query read from the pinned buffer or copied first, completion by
+    # polling or by stream synchronisation
+    for q_src, poll in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        knobs.set("CSLAM_SMALL_BEST_Q", q_src)
+        knobs.set("CSLAM_SMALL_BEST_POLL", poll)
+        for _ in range(3):
+            rows3, sims3 = p.search_batch(Q, 1)
+            assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best"
+            np.testing.assert_array_equal(rows3, rows)
+            assert sims3.tobytes() == sims.tobytes()
+    # the general path gives the same bytes
+    knobs.set("CSLAM_SMALL_BEST", "0")
+    rows2, sims2 = p.search_batch(Q, 1)
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    np.testing.assert_array_equal(rows2, rows)
+    assert sims2.tobytes() == sims.tobytes()
+    p.close()
+
+
+def test_small_pool_launch_has_its_limits(gpu):
+    """Beyond 4096 rows, 24 MB of rows or 8192 query floats per call, or for k > 1, the general path runs."""
+    rs = np.random.RandomState(0)
+    X = rs.rand(4097, 128).astype(np.float32)
+    p = _pool(X)
+    Q = rs.rand(3, 128).astype(np.float32)
+    rows, sims = p.search_batch(Q, 1)
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 1)
+    np.testing.assert_array_equal(rows, o_idx[:, :1])
+    p.close()
+    X = rs.rand(500, 4096).astype(np.float32)
+    p = _pool(X)
+    for m, fused in ((2, True), (3, False)):
+        Q = rs.rand(m, 4096).astype(np.float32)
+        rows, sims = p.search_batch(Q, 1)
+        assert (gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best") == fused
+        o_idx, o_sim, _ = oracle_knn.search(X, Q, 1)
+        np.testing.assert_array_equal(rows, o_idx[:, :1])
+        assert sims.tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
+    rows, sims = p.search_batch(Q[:1], 4)
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    p.close()
+    X = rs.rand(1600, 4096).astype(np.float32)
+    p = _pool(X)
+    rows, sims = p.search_batch(Q[:1], 1)
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    p.close()
+
+
+def test_growing_pool_keyframe_by_keyframe(gpu):
+    """The reference's pattern (loop_closure_sparse_matching.py:26-32, 78-97): add a descriptor, match the
+    next one, from the empty pool on — every answer equal to the oracle's on the pool so far."""
+    rs = np.random.RandomState(3)
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    d = 128
+    D = rs.rand(80, d).astype(np.float32) - 0.4
+    D[40] = D[3]
+    p = NearestNeighborsMatching()
+    assert p.search_best(D[0]) == (None, None)
+    for i in range(80):
+        if i > 0:
+            item, sim = p.search_best(D[i])
+            o_idx, o_sim, _ = oracle_knn.search(D[:i], D[i:i + 1], 1)
+            assert item == int(o_idx[0, 0]), i
+            assert np.float32(sim).tobytes() == np.float32(o_sim[0, 0]).tobytes()
+            assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best"
+        p.add_item(D[i], i)
+    item, sim = p.search_best(D[3])
+    assert item == 3
+    p.close()
