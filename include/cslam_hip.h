@@ -85,7 +85,9 @@ int cslam_pool_device_view(const cslam_pool_t* pool, const float** rows_dev, int
  *   out_idx  [n_queries][k] int32 row numbers, best first; ties → lowest row first
  *   out_sim  [n_queries][k] fp32 cosine similarities
  *   out_count[n_queries]    number of valid results = min(k, size)
- * Entries past out_count are -1 / -inf.  Empty pool → all counts 0 (nns_matching.py:54-55). */
+ * Entries past out_count are -1 / -inf.  Empty pool → all counts 0 (nns_matching.py:54-55).
+ * Synchronous: the results are in out_* on return (small calls wait on a pinned word the last kernel
+ * writes, larger ones on the pool's stream). */
 int cslam_pool_search(cslam_pool_t* pool, const float* queries, int n_queries, int k,
                       int32_t* out_idx, float* out_sim, int32_t* out_count);
 /* same with queries and outputs resident in HBM; asynchronous on `stream`.
