@@ -755,7 +755,7 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
 #if defined(CSLAM_MQ_WAVES8)
     if (waves == 8) {
         switch (tiles) {
-            case 2: return launch_mode<2, 64, 4, 8, 8>(a, mode, nt, st);
+            case 2: return launch_mode<2, 64, 3, 8, 8>(a, mode, nt, st);
             case 3: return launch_mode<3, 64, 3, 5, 8>(a, mode, nt, st);
             case 4: return launch_mode<4, 64, 3, 4, 8>(a, mode, nt, st);
             default: return launch_mode<5, 64, 3, 3, 8>(a, mode, nt, st);

@@ -2,13 +2,14 @@
 One process, settings alternating (CSLAM_KNOBS_LIVE), results of every setting compared bit for bit
 with the first.  For each pool size: 80 (and 48) best-match queries, step time and summed kernel time
 (HIP events on the launch stream) per setting.
-usage: mq_plan_ab.py [rows ...]      env MQ_M=80,48"""
+usage: mq_plan_ab.py [rows ...]      env MQ_M=80,48  MQ_AB=name=KEY:VALUE,KEY:VALUE;name2=...  CSLAM_PROBE_LIB=other.so"""
 import ctypes, os, sys, time
 os.environ["CSLAM_KNOBS_LIVE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cslam_amd import _lib
 from cslam_amd.nns_matching import NearestNeighborsMatching
+if os.environ.get('CSLAM_PROBE_LIB'): _lib.LIB_PATH = os.environ['CSLAM_PROBE_LIB']   # another build of the library
 L = _lib.load(); D = 4096
 MS = [int(x) for x in os.environ.get("MQ_M", "80").split(",")]
 sizes = [int(a) for a in sys.argv[1:]] or [25000, 100000, 60000, 12000, 5000]
@@ -20,6 +21,9 @@ SETTINGS = [
     ("all-K-split forced, two waves per SIMD", {"CSLAM_MQ_ALLPART": "2"}),
     ("all-K-split forced, one wave per SIMD", {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_PART_WAVES": "4"}),
 ]
+if os.environ.get("MQ_AB"):   # other settings: MQ_AB="name=KEY:VALUE,KEY:VALUE;name2=..." (an empty list = the default)
+    SETTINGS = [(part.split("=")[0], dict(kv.split(":") for kv in part.split("=")[1].split(",") if kv))
+                for part in os.environ["MQ_AB"].split(";")]
 KEYS = sorted({k for _, e in SETTINGS for k in e})
 g = torch.Generator(device="cuda").manual_seed(0)
 for N in sizes:
