@@ -1,7 +1,8 @@
 """Randomised parity sweep of the HIP kNN against the C oracle (bit-exact similarities and
 indices) over ragged shapes, k values, duplicated / zero / huge-norm rows and incremental adds.
 Every case also runs the split best-match search (cslam_pool_search_best_split_dev: best row before
-/ from a random split, random upper row bound) against the oracle on the two row ranges.
+/ from a random split, random upper row bound) against the oracle on the two row ranges, and (round 4)
+a top-k search on a random row window (cslam_pool_search_range_dev).
 Not part of the test suite (minutes); run by hand:  python tools/fuzz_knn.py [cases] [seed]"""
 import ctypes
 import os
@@ -28,7 +29,7 @@ for c in range(cases):
     m = int(rs.choice([1, 2, 15, 16, 17, 31, 33, 40, 48, 64, 65, 80, 81, 96, 130, 160, 300]))
     while n * dim * m > 3_000_000_000 and m > 1:   # keep the strict-chain oracle to seconds per case
         m = max(1, m // 2)
-    k = int(rs.choice([1, 1, 2, 3, 5, 10, 16, 17, 128, 129, 1000]))
+    k = int(rs.choice([1, 1, 1, 2, 3, 5, 10, 16, 17, 26, 32, 128, 129, 1000]))
     scale = float(rs.choice([1.0, 1e-3, 1e3]))
     x = (rs.rand(n, dim).astype(np.float32) - (0.5 if rs.rand() < 0.5 else 0.0)) * scale
     if n > 4:
@@ -55,6 +56,26 @@ for c in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH", dict(dim=dim, n=n, m=m, k=k, scale=scale, cut=cut), flush=True)
+    if ok and n >= 3:
+        # a row window through the device-pointer API (the shard's searches; k_small_best and
+        # k_topk_from_parts on windows that do not start at row 0)
+        lo = int(rs.randint(0, n - 1))
+        hi_w = int(rs.randint(lo + 1, n + 1))
+        kw = min(k, 64)
+        qd = torch.from_numpy(q).cuda()
+        wi = torch.empty((m, kw), dtype=torch.int32, device="cuda")
+        ws = torch.empty((m, kw), dtype=torch.float32, device="cuda")
+        _lib.check(L.cslam_pool_search_range_dev(pool.handle, ctypes.c_void_p(qd.data_ptr()), dim, m, kw, lo, hi_w,
+                                                 ctypes.c_void_p(wi.data_ptr()), ctypes.c_void_p(ws.data_ptr()), None))
+        torch.cuda.synchronize()
+        oi_w, os_w, oc_w = oracle_knn.search(x[lo:hi_w], q, kw)
+        kk_w = int(oc_w[0])
+        ok3 = np.array_equal(wi.cpu().numpy()[:, :kk_w], oi_w[:, :kk_w] + lo) and \
+            np.array_equal(ws.cpu().numpy()[:, :kk_w].view(np.uint32), os_w[:, :kk_w].view(np.uint32)) and \
+            bool(np.all(wi.cpu().numpy()[:, kk_w:] == -1))
+        if not ok3:
+            bad += 1
+            print("WINDOW MISMATCH", dict(dim=dim, n=n, m=m, k=kw, lo=lo, hi=hi_w, scale=scale), flush=True)
     if ok and n >= 2:
         ms = min(m, 100)
         hi = int(rs.randint(2, n + 1))

@@ -3,7 +3,8 @@ launches per shape, every result compared bit for bit with the first one (an int
 the hand-counted vmcnt / LDS-DMA pipelines would show as a flipped bit sooner or later) and the
 first one with the oracle.  Shapes cover k_scan_dma (big pool), k_scan_dma_ks (small pool, long
 descriptors), the split best-match scan, the narrow-slice variants (128 / 64 floats per slice), a ragged length
-(staged queries), the register-ring scan (dim <= 16), k = 10 and - round 3 - the multi-tile scan k_scan_mq."""
+(staged queries), the register-ring scan (dim <= 16), k = 10, - round 3 - the multi-tile scan k_scan_mq and
+- round 4 - its all-K-split form, k_topk_from_parts at 17+ queries and the one-launch k_small_best."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +22,11 @@ for (n, d, m, k, split) in [(100_000, 4096, 16, 1, -1), (100_000, 4096, 16, 1, 9
                             # round 3: k_scan_mq (T = 2..5), plain / split / k > 1, with and without the K-split tail
                             (100_000, 4096, 80, 1, -1), (100_000, 4096, 80, 1, 99_990), (100_000, 4096, 32, 1, -1),
                             (25_000, 4096, 80, 1, 24_990), (60_000, 1024, 48, 1, -1), (200_000, 128, 64, 1, -1),
-                            (30_000, 512, 40, 10, -1), (7001, 192, 80, 1, -1)]:
+                            (30_000, 512, 40, 10, -1), (7001, 192, 80, 1, -1),
+                            # round 4: the all-K-split pass, top-k from parts at 17+ queries, k_small_best (atomics + ticket)
+                            (25_000, 4096, 80, 1, -1), (25_000, 4096, 80, 26, -1), (100_000, 4096, 80, 26, -1),
+                            (12_000, 1024, 48, 10, -1), (1000, 128, 1, 1, -1), (4000, 128, 16, 1, -1),
+                            (1000, 4096, 2, 1, -1), (300, 1000, 4, 1, -1)]:
     rs = np.random.RandomState(n + d)
     X = rs.rand(n, d).astype(np.float32); Q = rs.rand(m, d).astype(np.float32)
     pool = NearestNeighborsMatching(dim=d, capacity_hint=n); pool.add_items(X, list(range(n)))
