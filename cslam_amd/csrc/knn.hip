@@ -1488,14 +1488,24 @@ struct PanelParts {
     }
 };
 
+// (the body: ONE query - its part maxima cq[0..n_parts), its dots dq[0..n), 1/||q|| = rq - by one 256-thread
+// block; results to oi/os[0..k).  Block-uniform control flow; callers that run it for several queries in a row
+// put a barrier between two calls.)
+// k_small_search<true>: part s is strip s of the window (16 rows)
+struct StripParts {
+    int64_t n;
+    __device__ void range(int c, int64_t& lo, int& cnt) const {
+        lo = (int64_t)c << 4;
+        const int64_t left = n - lo;
+        cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+    }
+};
+
 template <class Parts>
-__global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restrict__ cand, int64_t cand_stride,
-                                                         int n_parts, const Parts parts,
-                                                         const float* __restrict__ dots, int64_t dots_stride,
-                                                         const float* __restrict__ rnx,
-                                                         const float* __restrict__ rnq, uint32_t row0, int64_t n,
-                                                         int k, int32_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_sim) {
+__device__ inline void topk_from_parts_body(const uint64_t* cq, int n_parts, const Parts& parts,
+                                            const float* dq, const float* __restrict__ rnx,
+                                            const float rq, uint32_t row0, int64_t n, int k,
+                                            int32_t* __restrict__ oi, float* __restrict__ os) {
     __shared__ uint64_t lst[kTopkWavesMax];
     __shared__ uint16_t lst_w[kTopkWavesMax];
     __shared__ uint64_t wmax[2][4];
@@ -1505,8 +1515,6 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
     __shared__ int w_cnt[kTopkWavesMaxK], w_pre[kTopkWavesMaxK + 1];
     __shared__ int cnt1, cnt2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q = blockIdx.x;
-    const uint64_t* cq = cand + q * cand_stride;
     if (tid == 0) {
         cnt1 = 0;
         cnt2 = 0;
@@ -1579,7 +1587,6 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
     __syncthreads();
     const int total = w_pre[nwin];
     const uint64_t tk = tk_s;
-    const float rq = rnq[q];
     // window-relative row of candidate number idx: the last winner whose first candidate is <= idx
     // (nwin <= 32: five steps)
     auto row_at = [&](int idx) -> int64_t {
@@ -1591,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
     };
     auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
         const int64_t row = row_at(idx);
-        return make_comp((dots[q * dots_stride + row] * rnx[row]) * rq, row0 + (uint32_t)row);
+        return make_comp((dq[row] * rnx[row]) * rq, row0 + (uint32_t)row);
     };
     int s2 = kTopkWavesMax + 1;
     if (!every_row) {
@@ -1610,7 +1617,7 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
 #pragma unroll
             for (int e = 0; e < kBatch; ++e) {
                 const int64_t r_ = row[e] >= 0 ? row[e] : 0;
-                dv[e] = dots[q * dots_stride + r_];
+                dv[e] = dq[r_];
                 rx[e] = rnx[r_];
             }
 #pragma unroll
@@ -1632,13 +1639,13 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
             int rank = 0;
             for (int j = 0; j < s2; ++j) rank += lst[j] > c ? 1 : 0;
             if (rank < k) {
-                out_idx[q * k + rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFu));
-                out_sim[q * k + rank] = ord2f((uint32_t)(c >> 32));
+                oi[rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFu));
+                os[rank] = ord2f((uint32_t)(c >> 32));
             }
         }
         for (int j = s2 + tid; j < k; j += 256) {   // fewer rows than k
-            out_idx[q * k + j] = -1;
-            out_sim[q * k + j] = -INFINITY;
+            oi[j] = -1;
+            os[j] = -INFINITY;
         }
         return;
     }
@@ -1657,15 +1664,29 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
 #pragma unroll
         for (int x = 1; x < 4; ++x) win = wmax[rd & 1][x] > win ? wmax[rd & 1][x] : win;
         if (tid == 0) {
-            out_idx[q * k + rd] = win ? (int32_t)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu)) : -1;
-            out_sim[q * k + rd] = win ? ord2f((uint32_t)(win >> 32)) : -INFINITY;
+            oi[rd] = win ? (int32_t)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu)) : -1;
+            os[rd] = win ? ord2f((uint32_t)(win >> 32)) : -INFINITY;
         }
         last = win;   // 0 when nothing is left: the remaining rounds write the empty result
     }
 }
 
+template <class Parts>
+__global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restrict__ cand, int64_t cand_stride,
+                                                         int n_parts, const Parts parts,
+                                                         const float* __restrict__ dots, int64_t dots_stride,
+                                                         const float* __restrict__ rnx,
+                                                         const float* __restrict__ rnq, uint32_t row0, int64_t n,
+                                                         int k, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_sim) {
+    const int64_t q = blockIdx.x;
+    topk_from_parts_body(cand + q * cand_stride, n_parts, parts, dots + q * dots_stride, rnx, rnq[q], row0, n, k,
+                         out_idx + q * k, out_sim + q * k);
+}
+
 // ---------------------------------------------------------------------------------------------
-// k_small_best: search_best of <= 16 queries over a SMALL window (<= 4096 rows) in ONE launch - the
+// k_small_search<TOPK> (reported as k_small_best / k_small_topk): search_best - or search with 2 <= k <= 32,
+// the intra-robot match of lcsm.py:78-97 - of <= 16 queries over a SMALL window (<= 4096 rows) in ONE launch - the
 // per-keyframe call of the reference at its own scale (nns_matching.py:66-78 on a pool of a few
 // hundred 128-d descriptors: BASELINE configs[0]).  The general path is a copy of the queries into
 // HBM + k_stage_queries + a scan + k_best_pair: four dependent operations of 4-8 us each around
@@ -1680,13 +1701,15 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
 // ---------------------------------------------------------------------------------------------
 constexpr int kSmallBestMaxRows = 4096, kSmallBestMaxChunks = 16, kSmallBestMaxQFloats = 8192;
 constexpr int64_t kSmallBestMaxFloats = (int64_t)6 << 20;
-__global__ __launch_bounds__(256) void k_small_best(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
-                                                    const float* __restrict__ Q, int64_t q_stride, int dim, int m,
-                                                    int vec_ok, const float* __restrict__ rnx, uint32_t row0,
-                                                    int spb, int nchunks, uint64_t* __restrict__ best,
-                                                    uint32_t* __restrict__ ticket, int32_t* __restrict__ out_idx,
-                                                    float* __restrict__ out_sim, uint32_t* __restrict__ done,
-                                                    uint32_t seq) {
+template <bool TOPK>
+__global__ __launch_bounds__(256) void k_small_search(const float* __restrict__ X, int64_t xs, int64_t n, int dp,
+                                                      const float* __restrict__ Q, int64_t q_stride, int dim, int m,
+                                                      int vec_ok, const float* __restrict__ rnx, uint32_t row0,
+                                                      int spb, int nchunks, uint64_t* __restrict__ best,
+                                                      uint32_t* __restrict__ ticket, int32_t* __restrict__ out_idx,
+                                                      float* __restrict__ out_sim, uint32_t* __restrict__ done,
+                                                      uint32_t seq, int k, uint64_t* cand, int64_t cand_stride,
+                                                      float* dots, int64_t dots_stride) {
     extern __shared__ f32x4 sb_part[];   // [spb * nchunks][64]
     __shared__ float rq_s[16];
     __shared__ int last_s;
@@ -1768,8 +1791,19 @@ __global__ __launch_bounds__(256) void k_small_best(const float* __restrict__ X,
         bst = o > bst ? o : bst;
         o = __shfl_xor(bst, 32, 64);
         bst = o > bst ? o : bst;
-        if (g == 0 && r < m)
+        if (TOPK) {
+            // search with 2 <= k <= 32: the strip's composite and the raw dots of its rows stay in memory for
+            // the last block's rank select (topk_from_parts_body over the strips)
+            if (r < m) {
+                if (g == 0) cand[(int64_t)r * cand_stride + strip] = bst;
+                float* out = dots + (int64_t)r * dots_stride + lo + 4 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * g + e < rows) out[e] = tot[e];
+            }
+        } else if (g == 0 && r < m) {
             __hip_atomic_fetch_max(&best[r], bst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // the last block to get here sees every block's maxima: every thread's atomics are performed
     // (fence) before its block takes a ticket
@@ -1781,7 +1815,17 @@ __global__ __launch_bounds__(256) void k_small_best(const float* __restrict__ X,
     }
     __syncthreads();
     if (!last_s) return;
-    if (tid < m) {
+    if (TOPK) {
+        // every block's composites and dots were released before its ticket; acquire them (this block's
+        // caches may hold lines of an earlier call), then one rank select per query
+        __threadfence();
+        const StripParts parts{n};
+        for (int j = 0; j < m; ++j) {
+            topk_from_parts_body(cand + (int64_t)j * cand_stride, (int)S, parts, dots + (int64_t)j * dots_stride, rnx,
+                                 rq_s[j], row0, n, k, out_idx + (int64_t)j * k, out_sim + (int64_t)j * k);
+            __syncthreads();
+        }
+    } else if (tid < m) {
         const uint64_t w = __hip_atomic_load(&best[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         out_idx[tid] = comp_row(w);
         out_sim[tid] = comp_sim(w);
@@ -2825,20 +2869,21 @@ int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
     return CSLAM_OK;
 }
 
-// search_best of a few queries over a small window in ONE launch (k_small_best).  CSLAM_SMALL_BEST=0:
-// the general path (stage + scan + final level) - A/B runs and the tests that compare the two.
-bool small_best_applies(const cslam_pool* p, int m) {
-    static Knob k_small{"CSLAM_SMALL_BEST", 1};
+// search_best (k = 1) or search with 2 <= k <= 32 of a few queries over a small window in ONE launch
+// (k_small_search).  CSLAM_SMALL_BEST=0: the general path (stage + scan + final level / rank select) - A/B
+// runs and the tests that compare the two; CSLAM_SMALL_BEST=1: k = 1 only.
+bool small_search_applies(const cslam_pool* p, int m, int k) {
+    static Knob k_small{"CSLAM_SMALL_BEST", 2};
     const int nchunks = (p->dp + 511) / 512;
     // (24 MB of rows at most: 4000 x 4096-d is 1.7 us faster on the general path's LDS-DMA K-split scan,
     // 1000 x 4096-d 5 us slower, profiles/r04_small_best_ab.txt)
-    return knob(k_small) != 0 && m >= 1 && m <= 16 && p->vn >= 1 && p->vn <= kSmallBestMaxRows &&
-           nchunks <= kSmallBestMaxChunks && (int64_t)m * p->dp <= kSmallBestMaxQFloats &&
-           p->vn * p->dp <= kSmallBestMaxFloats;
+    return knob(k_small) != 0 && (k == 1 || (k >= 2 && k <= kTopkWavesMaxK && knob(k_small) >= 2)) && m >= 1 &&
+           m <= 16 && p->vn >= 1 && p->vn <= kSmallBestMaxRows && nchunks <= kSmallBestMaxChunks &&
+           (int64_t)m * p->dp <= kSmallBestMaxQFloats && p->vn * p->dp <= kSmallBestMaxFloats;
 }
 // (q may be any device-visible memory: HBM, or pinned host memory read over the host link)
-int small_best(cslam_pool* p, const float* q, int64_t q_stride, int m, int32_t* out_idx, float* out_sim,
-               hipStream_t st, uint32_t* done = nullptr, uint32_t seq = 0) {
+int small_search(cslam_pool* p, const float* q, int64_t q_stride, int m, int k, int32_t* out_idx, float* out_sim,
+                 hipStream_t st, uint32_t* done = nullptr, uint32_t seq = 0) {
     if (p->small_scratch.p == nullptr) {
         CSLAM_TRY(p->small_scratch.reserve(256));
         CSLAM_HIP_TRY(hipMemsetAsync(p->small_scratch.p, 0, 256, st));
@@ -2848,19 +2893,32 @@ int small_best(cslam_pool* p, const float* q, int64_t q_stride, int m, int32_t* 
     const int64_t strips = (p->vn + 15) / 16;
     const unsigned grid = (unsigned)((strips + spb - 1) / spb);
     const int vec_ok = ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
+    const int64_t cstride = (strips + 63) / 64 * 64, dstride = (p->vn + 63) / 64 * 64;
+    if (k > 1) {   // the strips' composites and the raw dots, for the last block's rank select
+        CSLAM_TRY(p->cand_a.reserve((size_t)16 * cstride * sizeof(uint64_t)));
+        CSLAM_TRY(p->sims.reserve((size_t)16 * dstride * sizeof(float)));
+    }
     const bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
-    hipLaunchKernelGGL(k_small_best, dim3(grid), dim3(256), (size_t)spb * nchunks * 64 * sizeof(f32x4), st,
-                       p->rows + p->v0 * p->xs, p->xs, p->vn, p->dp, q, q_stride, p->dim, m, vec_ok,
-                       p->inv_norm + p->v0, (uint32_t)p->v0, spb, nchunks, p->small_scratch.as<uint64_t>(),
-                       reinterpret_cast<uint32_t*>(p->small_scratch.as<uint64_t>() + 16), out_idx, out_sim, done,
-                       seq);
+    const size_t lds = (size_t)spb * nchunks * 64 * sizeof(f32x4);
+    uint64_t* best = p->small_scratch.as<uint64_t>();
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(best + 16);
+    if (k == 1)
+        hipLaunchKernelGGL((k_small_search<false>), dim3(grid), dim3(256), lds, st, p->rows + p->v0 * p->xs, p->xs,
+                           p->vn, p->dp, q, q_stride, p->dim, m, vec_ok, p->inv_norm + p->v0, (uint32_t)p->v0, spb,
+                           nchunks, best, ticket, out_idx, out_sim, done, seq, 1, (uint64_t*)nullptr, (int64_t)0,
+                           (float*)nullptr, (int64_t)0);
+    else
+        hipLaunchKernelGGL((k_small_search<true>), dim3(grid), dim3(256), lds, st, p->rows + p->v0 * p->xs, p->xs,
+                           p->vn, p->dp, q, q_stride, p->dim, m, vec_ok, p->inv_norm + p->v0, (uint32_t)p->v0, spb,
+                           nchunks, best, ticket, out_idx, out_sim, done, seq, k, p->cand_a.as<uint64_t>(), cstride,
+                           p->sims.as<float>(), dstride);
     CSLAM_HIP_TRY(hipGetLastError());
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
         p->prof_n++;
     }
-    p->last_scan_kernel = "k_small_best";
+    p->last_scan_kernel = k == 1 ? "k_small_best" : "k_small_topk";
     return CSLAM_OK;
 }
 
@@ -2917,7 +2975,7 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
-    if (k == 1 && small_best_applies(p, m)) return small_best(p, q_dev, q_stride, m, out_idx, out_sim, st);
+    if (small_search_applies(p, m, k)) return small_search(p, q_dev, q_stride, m, k, out_idx, out_sim, st);
     if (k == 1 && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m))
         return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
     if (k == 1 && mq_best_applies(p, m))
@@ -3279,7 +3337,7 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
         float* sim_pin = reinterpret_cast<float*>(static_cast<char*>(p->pin_out.p) + sim_off);
         p->v0 = 0;
         p->vn = p->n;
-        if (k == 1 && small_best_applies(p, n_queries)) {
+        if (small_search_applies(p, n_queries, k)) {
             // A small pool's best match - the reference's per-keyframe call at its own scale - is ONE launch
             // (k_small_best).  Queries of up to 1 KiB are read by the kernel from the pinned buffer itself
             // (no copy operation in front of the launch; larger ones would cross the host link once per
@@ -3294,8 +3352,8 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
             const uint32_t seq = ++p->small_seq ? p->small_seq : ++p->small_seq;   // never 0
             const bool poll = knob(k_poll) != 0;
             if (poll) __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
-            CSLAM_TRY(small_best(p, from_pin ? p->pin_q.as<float>() : p->h_q.as<float>(), p->dim, n_queries,
-                                 idx_pin, sim_pin, p->stream, poll ? done : nullptr, seq));
+            CSLAM_TRY(small_search(p, from_pin ? p->pin_q.as<float>() : p->h_q.as<float>(), p->dim, n_queries, k,
+                                   idx_pin, sim_pin, p->stream, poll ? done : nullptr, seq));
             bool seen = false;
             if (poll) {
                 // (a kernel that never writes the word - a fault - ends in the synchronisation below, which

@@ -95,7 +95,7 @@ class NearestNeighborsMatching(object):
         self._pool = None
         self._capacity_hint = int(capacity_hint)
         self.data = []  # like the reference until the dimension is known
-        self._one = None  # result buffers of search_best
+        self._one = {}  # k -> result buffers of the one-query calls (search_best, search)
         if dim is not None:
             self._create(int(dim))
 
@@ -247,6 +247,24 @@ class NearestNeighborsMatching(object):
         kk = int(cnt[0])
         return idx[:, :kk], sim[:, :kk]
 
+    def _search_one(self, query, k):
+        """One query, top-k, n > 0: (idx[k] int32, sim[k] float32, kk) in buffers kept per pool and k - the
+        calls the reference makes per keyframe (`search_best`, `search(q, nb_best_matches)`): allocating the
+        result arrays and their ctypes pointers per call was a third of the call's time at the reference's
+        own pool sizes.  The buffers are overwritten by the next call."""
+        buf = self._one.get(k)
+        if buf is None:
+            idx, sim, cnt = np.empty(k, np.int32), np.empty(k, np.float32), np.empty(1, np.int32)
+            buf = self._one[k] = (idx, sim, _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt))
+        q = query if (type(query) is np.ndarray and query.dtype == np.float32 and query.flags["C_CONTIGUOUS"]) \
+            else _to_numpy_f32(query)
+        if q.size != self.dim:
+            raise ValueError(f"query size {q.size} != pool dim {self.dim}")
+        rc = self._lib.cslam_pool_search(self._pool, q.ctypes.data, 1, k, buf[2], buf[3], buf[4])
+        if rc != 0:
+            _lib.check(rc)
+        return buf[0], buf[1], (k if k < self.n else self.n)
+
     def search(self, query, k):
         """Cosine top-k of one query against rows [0, n).
 
@@ -255,8 +273,13 @@ class NearestNeighborsMatching(object):
         """
         if len(self.data) == 0:
             return [], []
-        rows, sims = self.search_batch(_to_numpy_f32(query).reshape(1, -1), k)
-        return [self.items[int(r)] for r in rows[0]], sims[0]
+        k = int(k)
+        if self.n == 0 or k <= 0 or k > 1024:
+            rows, sims = self.search_batch(_to_numpy_f32(query).reshape(1, -1), k)
+            return [self.items[int(r)] for r in rows[0]], sims[0]
+        idx, sim, kk = self._search_one(query, k)
+        items = self.items
+        return [items[r] for r in idx[:kk].tolist()], sim[:kk].copy()
 
     def search_best(self, query):
         """`search(query, 1)` unpacked: (item, similarity) of the most similar row, or
@@ -266,20 +289,8 @@ class NearestNeighborsMatching(object):
         if self.n == 0:
             items, similarities = self.search(query, 1)
             return items[0], similarities[0]
-        # one query, k = 1 - the call the reference makes per keyframe: result buffers and their pointers
-        # are made once per pool (a third of the call's time at the reference's own pool sizes otherwise)
-        one = self._one
-        if one is None:
-            idx, sim, cnt = np.empty(1, np.int32), np.empty(1, np.float32), np.empty(1, np.int32)
-            one = self._one = (idx, sim, _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt))
-        q = query if (type(query) is np.ndarray and query.dtype == np.float32 and query.flags["C_CONTIGUOUS"]) \
-            else _to_numpy_f32(query)
-        if q.size != self.dim:
-            raise ValueError(f"query size {q.size} != pool dim {self.dim}")
-        rc = self._lib.cslam_pool_search(self._pool, q.ctypes.data, 1, 1, one[2], one[3], one[4])
-        if rc != 0:
-            _lib.check(rc)
-        return self.items[int(one[0][0])], one[1][0]
+        idx, sim, _ = self._search_one(query, 1)
+        return self.items[int(idx[0])], sim[0]
 
     def search_best_batch(self, queries):
         """search_best for every row of `queries`: (items list, sims[M]); empty pool →

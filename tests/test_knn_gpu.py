@@ -346,6 +346,7 @@ def test_fused_top_k_select_matches_oracle(gpu, knobs, n, d, m, k):
     first; a row window (cslam_pool_search_range_dev) selects inside the window."""
     import ctypes
     torch = pytest.importorskip("torch")
+    knobs.set("CSLAM_SMALL_BEST", "0")   # (round 4: windows of <= 4096 rows are k_small_search's; this kernel's small shapes stay covered)
     rs = np.random.RandomState(n + d + k)
     X = (rs.rand(n, d).astype(np.float32) - 0.3)
     if n > 300:

@@ -1,4 +1,4 @@
-"""search_best on a SMALL pool in one launch (k_small_best, round 4): the reference's per-keyframe call
+"""search_best - and search with 2 <= k <= 32 - on a SMALL pool in one launch (k_small_search, round 4): the reference's per-keyframe call
 (nns_matching.py:66-78: search(query, 1) on a pool of a few hundred 128-d descriptors, BASELINE
 configs[0]) without the query copy, the stage kernel and the final-level kernel of the general path.
 Bit for bit against the C oracle and against the general path (CSLAM_SMALL_BEST=0); queries from host
@@ -114,7 +114,7 @@ def test_small_pool_best_match_in_one_launch(gpu, knobs, n, d, m):
 
 
 def test_small_pool_launch_has_its_limits(gpu):
-    """Beyond 4096 rows, 24 MB of rows or 8192 query floats per call, or for k > 1, the general path runs."""
+    """Beyond 4096 rows, 24 MB of rows or 8192 query floats per call, or for k > 32, the general path runs."""
     rs = np.random.RandomState(0)
     X = rs.rand(4097, 128).astype(np.float32)
     p = _pool(X)
@@ -134,12 +134,77 @@ def test_small_pool_launch_has_its_limits(gpu):
         np.testing.assert_array_equal(rows, o_idx[:, :1])
         assert sims.tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
     rows, sims = p.search_batch(Q[:1], 4)
-    assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_topk"
+    rows, sims = p.search_batch(Q[:1], 33)
+    assert not gpu.cslam_pool_scan_kernel(p.handle).decode().startswith("k_small")
     p.close()
     X = rs.rand(1600, 4096).astype(np.float32)
     p = _pool(X)
     rows, sims = p.search_batch(Q[:1], 1)
     assert gpu.cslam_pool_scan_kernel(p.handle).decode() != "k_small_best"
+    p.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (1000, 128, 1, 10),     # the intra-robot match of lcsm.py:78-97 at cfg1's scale: nb_best_matches = 10
+    (1000, 128, 1, 2), (1000, 128, 1, 32),
+    (4096, 128, 16, 10),    # 256 strips, a full query tile: sixteen rank selects by the last block
+    (17, 128, 3, 16),       # two strips, k of 17 rows
+    (5, 128, 4, 10),        # k > n: (-1, -inf) tails
+    (1, 64, 1, 2),
+    (1500, 4096, 1, 10),    # eight chunks per strip
+    (300, 1000, 4, 5),
+    (100, 33, 5, 3), (50, 10, 2, 7),
+    (4000, 64, 3, 16),      # the zero query: 250 strips tie at the bound, rows 0..15 in order
+])
+def test_small_pool_top_k_in_one_launch(gpu, knobs, n, d, m, k):
+    """search with 2 <= k <= 32 on a small pool (k_small_search<true>, reported as k_small_topk): the blocks
+    leave the strips' composites and the raw dots, the last block to finish ranks the rows of the k best
+    strips (topk_from_parts_body, the code of k_topk_from_parts).  Against the oracle bit for bit, against
+    the general path, host- and device-pointer API, a row window, call after call."""
+    torch = pytest.importorskip("torch")
+    X, Q = _data(n, d, m, 11 * n + d + m + k)
+    if n > 300:
+        X[n // 2] = X[5]           # three equal rows in different strips: lowest row first
+    o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+    kk = int(o_cnt[0])
+    p = _pool(X)
+    for _ in range(3):
+        rows, sims = p.search_batch(Q, k)
+        assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_topk"
+        assert rows.shape == (m, kk)
+        np.testing.assert_array_equal(rows, o_idx[:, :kk])
+        assert sims.tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    if n > 300:
+        assert list(rows[m - 1][:3]) == [5, n // 2, n - 2][:min(k, 3)]
+        if m > 2:
+            assert list(rows[1]) == list(range(kk))
+    # reference-shaped call: search(query, k) -> items, similarities
+    items, s1 = p.search(Q[0], k)
+    assert items == [int(r) for r in o_idx[0, :kk]] and np.asarray(s1).tobytes() == o_sim[0, :kk].astype(np.float32).tobytes()
+    # device-pointer API on a row window
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lo, hi = n // 3, n - n // 5
+    if hi > lo:
+        q = torch.from_numpy(Q).cuda()
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+        sim = torch.empty((m, k), dtype=torch.float32, device="cuda")
+        assert gpu.cslam_pool_search_range_dev(p.handle, ctypes.c_void_p(q.data_ptr()), d, m, k, lo, hi,
+                                               ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()), st) == 0
+        torch.cuda.synchronize()
+        assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_topk"
+        w_idx, w_sim, w_cnt = oracle_knn.search(X[lo:hi], Q, k)
+        wk = int(w_cnt[0])
+        np.testing.assert_array_equal(idx.cpu().numpy()[:, :wk], w_idx[:, :wk] + lo)
+        assert sim.cpu().numpy()[:, :wk].tobytes() == w_sim[:, :wk].astype(np.float32).tobytes()
+        assert np.all(idx.cpu().numpy()[:, wk:] == -1)
+    # k = 1 only (the round's first form of the launch), then the general path: same bytes
+    for setting in ("1", "0"):
+        knobs.set("CSLAM_SMALL_BEST", setting)
+        rows2, sims2 = p.search_batch(Q, k)
+        assert not gpu.cslam_pool_scan_kernel(p.handle).decode().startswith("k_small")
+        np.testing.assert_array_equal(rows2, rows)
+        assert sims2.tobytes() == sims.tobytes()
     p.close()
 
 
@@ -160,6 +225,12 @@ def test_growing_pool_keyframe_by_keyframe(gpu):
             assert item == int(o_idx[0, 0]), i
             assert np.float32(sim).tobytes() == np.float32(o_sim[0, 0]).tobytes()
             assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_best"
+            items, sims = p.search(D[i], 10)            # match_local_loop_closures' call (lcsm.py:85)
+            o_idx, o_sim, o_cnt = oracle_knn.search(D[:i], D[i:i + 1], 10)
+            kk = int(o_cnt[0])
+            assert items == [int(r) for r in o_idx[0, :kk]], i
+            assert np.asarray(sims).tobytes() == o_sim[0, :kk].astype(np.float32).tobytes()
+            assert gpu.cslam_pool_scan_kernel(p.handle).decode() == "k_small_topk"
         p.add_item(D[i], i)
     item, sim = p.search_best(D[3])
     assert item == 3

@@ -20,14 +20,15 @@ SETTINGS = [
 ]
 KEYS = sorted({k for _, e in SETTINGS for k in e})
 rs = np.random.RandomState(0)
-shapes = [(1000, 128, 1), (200, 128, 1), (4000, 128, 1), (1000, 128, 8), (1000, 512, 1), (1000, 4096, 1), (4000, 4096, 1)]
-for n, d, m in shapes:
+shapes = [(1000, 128, 1, 1), (200, 128, 1, 1), (4000, 128, 1, 1), (1000, 128, 8, 1), (1000, 512, 1, 1), (1000, 4096, 1, 1), (4000, 4096, 1, 1),
+          (1000, 128, 1, 10), (200, 128, 1, 10), (4000, 128, 1, 10), (1000, 4096, 1, 10)]   # k = 10: the intra-robot match (lcsm.py:85)
+for n, d, m, K in shapes:
     X = rs.rand(n, d).astype(np.float32)
     Q = rs.rand(m, d).astype(np.float32)
     p = NearestNeighborsMatching(dim=d, capacity_hint=n)
     p.add_items(X, list(range(n)))
-    idx = np.empty((m, 1), np.int32); sim = np.empty((m, 1), np.float32); cnt = np.empty(m, np.int32)
-    args = (p.handle, _lib.ptr(Q), m, 1, _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt))
+    idx = np.empty((m, K), np.int32); sim = np.empty((m, K), np.float32); cnt = np.empty(m, np.int32)
+    args = (p.handle, _lib.ptr(Q), m, K, _lib.ptr(idx), _lib.ptr(sim), _lib.ptr(cnt))
     fn = L.cslam_pool_search
     res = {name: [] for name, _ in SETTINGS}
     wrap = {name: [] for name, _ in SETTINGS}
@@ -45,11 +46,11 @@ for n, d, m in shapes:
             res[name].append((t * 1e6, b == ref))
             if m == 1:
                 t0 = time.perf_counter()
-                for _ in range(1000): p.search_best(Q[0])
+                for _ in range(1000): p.search_best(Q[0]) if K == 1 else p.search(Q[0], K)
                 wrap[name].append((time.perf_counter() - t0) / 1000 * 1e6)
     for k in KEYS: os.environ.pop(k, None)
     for name, _ in SETTINGS:
-        print(f"n={n:5d} d={d:4d} m={m:2d} {name:28s} " + " ".join(f"{a:6.1f}" for a, _ in res[name]) + " us per C call  bits " +
+        print(f"n={n:5d} d={d:4d} m={m:2d} k={K:2d} {name:28s} " + " ".join(f"{a:6.1f}" for a, _ in res[name]) + " us per C call  bits " +
               ("same" if all(c for _, c in res[name]) else "DIFFER") +
-              ("   search_best() " + " ".join(f"{a:6.1f}" for a in wrap[name]) if wrap[name] else ""), flush=True)
+              ("   search_best() / search() " + " ".join(f"{a:6.1f}" for a in wrap[name]) if wrap[name] else ""), flush=True)
     p.close()
