@@ -1491,6 +1491,8 @@ struct PanelParts {
 // (the body: ONE query - its part maxima cq[0..n_parts), its dots dq[0..n), 1/||q|| = rq - by one 256-thread
 // block; results to oi/os[0..k).  Block-uniform control flow; callers that run it for several queries in a row
 // put a barrier between two calls.)
+__device__ inline void signal_done(uint32_t* done, uint32_t seq, uint32_t* ticket);   // (defined in front of k_best_pair)
+
 // k_small_search<true>: part s is strip s of the window (16 rows)
 struct StripParts {
     int64_t n;
@@ -1678,10 +1680,12 @@ __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restr
                                                          const float* __restrict__ rnx,
                                                          const float* __restrict__ rnq, uint32_t row0, int64_t n,
                                                          int k, int32_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_sim) {
+                                                         float* __restrict__ out_sim, uint32_t* done, uint32_t seq,
+                                                         uint32_t* ticket) {
     const int64_t q = blockIdx.x;
     topk_from_parts_body(cand + q * cand_stride, n_parts, parts, dots + q * dots_stride, rnx, rnq[q], row0, n, k,
                          out_idx + q * k, out_sim + q * k);
+    signal_done(done, seq, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1841,6 +1845,24 @@ __global__ __launch_bounds__(256) void k_small_search(const float* __restrict__ 
     }
 }
 
+// Completion word of the host-pointer API's small calls (cslam_pool_search): the results sit in pinned host
+// memory and the host polls `done` for the call's number instead of paying a stream synchronisation.  Every
+// block calls this behind its last result store; the LAST block of the launch to get here writes the word.
+__device__ inline void signal_done(uint32_t* done, uint32_t seq, uint32_t* ticket) {
+    if (done == nullptr) return;   // grid-uniform
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = gridDim.x * gridDim.y;
+        bool last = true;
+        if (total > 1) {
+            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // final level of search_best: one block per (query, window) reduces the waves' composites.
 // window 1 (blockIdx.y == 1) exists for the split search only.
 __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ cand_a,
@@ -1849,7 +1871,8 @@ __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ 
                                                    int32_t* __restrict__ idx_a,
                                                    float* __restrict__ sim_a,
                                                    int32_t* __restrict__ idx_c,
-                                                   float* __restrict__ sim_c) {
+                                                   float* __restrict__ sim_c, uint32_t* done, uint32_t seq,
+                                                   uint32_t* ticket) {
     __shared__ uint64_t scratch[4];
     const int q = blockIdx.x;
     const bool second = blockIdx.y == 1;
@@ -1858,6 +1881,7 @@ __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ 
         (second ? idx_c : idx_a)[q] = comp_row(best);
         (second ? sim_c : sim_a)[q] = comp_sim(best);
     }
+    signal_done(done, seq, ticket);
 }
 
 }  // namespace
@@ -1878,6 +1902,8 @@ struct cslam_pool {
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, part;
     DevBuf small_scratch;              // k_small_best: 16 composites + the ticket, zero between calls
     uint32_t small_seq = 0;            // call number the host polls for (host-pointer API)
+    uint32_t* done_word = nullptr;     // armed by cslam_pool_search's small path: the call's final launch signals it
+    bool done_taken = false;
     DevBuf h_q, h_idx, h_sim, h_rows;  // device staging of the host-pointer API
     PinBuf pin_q, pin_out;             // pinned bounce buffers of cslam_pool_search
     PinBuf pin_rows;                   // pinned ring of cslam_pool_add's small appends
@@ -2778,6 +2804,23 @@ int append_rows_dev(cslam_pool* p, const float* rows_dev, int64_t n_rows, int64_
     return CSLAM_OK;
 }
 
+// The completion word of a small host-pointer call (cslam_pool_search arms it): taken by the launch site of
+// the call's FINAL kernel - one-shot, so that no other launch of the call signals early.
+struct DoneArgs {
+    uint32_t* word = nullptr;
+    uint32_t seq = 0;
+    uint32_t* ticket = nullptr;
+};
+DoneArgs take_done(cslam_pool* p, bool final_launch) {
+    DoneArgs d;
+    if (!final_launch || p->done_word == nullptr || p->done_taken || p->small_scratch.p == nullptr) return d;
+    d.word = p->done_word;
+    d.seq = p->small_seq;
+    d.ticket = reinterpret_cast<uint32_t*>(p->small_scratch.as<uint64_t>() + 17);
+    p->done_taken = true;
+    return d;
+}
+
 // search_best (lcsm.py:49,69) of <= 16 queries over the row window [v0, v0+vn): the LDS-DMA scan
 // with the fused arg-max epilogue; leaves one composite per query and wave in cand_a (and, with
 // split >= 0 (window-relative row), the rows at or behind `split` apart in cand_c).  Queries are
@@ -2824,12 +2867,14 @@ int best_scan_candidates(cslam_pool* p, const float* q_dev, int64_t q_stride, in
 
 // ... and the final level: (row, similarity) per query, for both windows of a split search
 int best_scan(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
-              int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {
+              int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st,
+              bool final_launch = false) {
     int64_t cstride = 0, n_cand = 0;
     CSLAM_TRY(best_scan_candidates(p, q_dev, q_stride, m, split, &cstride, &n_cand, st));
+    const DoneArgs dn = take_done(p, final_launch);
     hipLaunchKernelGGL(k_best_pair, dim3(m, split >= 0 ? 2 : 1), dim3(256), 0, st,
                        p->cand_a.as<uint64_t>(), p->cand_c.as<uint64_t>(), cstride, n_cand, idx_a,
-                       sim_a, idx_c, sim_c);
+                       sim_a, idx_c, sim_c, dn.word, dn.seq, dn.ticket);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -2843,14 +2888,16 @@ bool mq_best_applies(const cslam_pool* p, int m) {
     return mq_scan_applies(p, m) && m <= 4 * 16 * mq_max_tiles();
 }
 int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
-                 int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st) {
+                 int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st,
+                 bool final_call = false) {
     CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
     CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
     for (int q0 = 0, mb = 0; q0 < m; q0 += mb) {
         mb = mq_pass_queries(m - q0);
         if (mb <= 16) {   // a last pass of <= 16 queries: the single-tile kernel
             CSLAM_TRY(best_scan(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, split, idx_a + q0, sim_a + q0,
-                                idx_c ? idx_c + q0 : nullptr, sim_c ? sim_c + q0 : nullptr, st));
+                                idx_c ? idx_c + q0 : nullptr, sim_c ? sim_c + q0 : nullptr, st,
+                                final_call && q0 + mb >= m));
             continue;
         }
         const MqPlan g = mq_plan(p, mb);
@@ -2860,10 +2907,11 @@ int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
         CSLAM_TRY(mq_pass(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, p->rnq.as<float>() + q0, nullptr, 0,
                           true, p->cand_a.as<uint64_t>(), cstride, split,
                           split >= 0 ? p->cand_c.as<uint64_t>() : nullptr, g, st));
+        const DoneArgs dn = take_done(p, final_call && q0 + mb >= m);
         hipLaunchKernelGGL(k_best_pair, dim3(mb, split >= 0 ? 2 : 1), dim3(256), 0, st,
                            p->cand_a.as<uint64_t>(), p->cand_c.as<uint64_t>(), cstride, g.n_cand,
                            idx_a + q0, sim_a + q0, idx_c ? idx_c + q0 : nullptr,
-                           sim_c ? sim_c + q0 : nullptr);
+                           sim_c ? sim_c + q0 : nullptr, dn.word, dn.seq, dn.ticket);
         CSLAM_HIP_TRY(hipGetLastError());
     }
     return CSLAM_OK;
@@ -2952,10 +3000,11 @@ int topk_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
                           g, st));
         const PanelParts parts{g.n_main,  vn,      g.n_blocks, g.p_max, g.waves, mq_panel_strips(g.tiles, g.waves),
                                g.n_blocks * g.p_max * g.waves};
+        const DoneArgs dn = take_done(p, q0 + mb >= m);
         hipLaunchKernelGGL((k_topk_from_parts<PanelParts>), dim3(mb), dim3(256), 0, st, p->cand_a.as<uint64_t>(),
                            cstride, (int)g.n_cand, parts, p->sims.as<float>(), sims_stride, p->inv_norm + v0,
                            p->rnq.as<float>() + q0, (uint32_t)v0, vn, k, out_idx + (int64_t)q0 * k,
-                           out_sim + (int64_t)q0 * k);
+                           out_sim + (int64_t)q0 * k, dn.word, dn.seq, dn.ticket);
         CSLAM_HIP_TRY(hipGetLastError());
     }
     return CSLAM_OK;
@@ -2977,9 +3026,9 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
     }
     if (small_search_applies(p, m, k)) return small_search(p, q_dev, q_stride, m, k, out_idx, out_sim, st);
     if (k == 1 && m <= 16 && dma_scan_applies(p) && !ks_scan_applies(p, m))
-        return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
+        return best_scan(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st, true);
     if (k == 1 && mq_best_applies(p, m))
-        return best_scan_mq(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st);
+        return best_scan_mq(p, q_dev, q_stride, m, -1, out_idx, out_sim, nullptr, nullptr, st, true);
     int64_t sims_stride = (p->vn + 63) / 64 * 64;
     const int64_t qc = query_chunk(sims_stride);
     int64_t chunk = m < qc ? m : qc;
@@ -2995,9 +3044,11 @@ int search_dev_impl(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, 
         int64_t cstride = 0, n_cand = 0;
         CSLAM_TRY(best_scan_candidates(p, q_dev, q_stride, m, -1, &cstride, &n_cand, st, sims, sims_stride));
         const WaveParts parts{p->vn / n_cand, p->vn % n_cand};
+        const DoneArgs dn = take_done(p, true);
         hipLaunchKernelGGL((k_topk_from_parts<WaveParts>), dim3(m), dim3(256), 0, st, p->cand_a.as<uint64_t>(),
                            cstride, (int)n_cand, parts, sims, sims_stride, p->inv_norm + p->v0,
-                           p->rnq.as<float>(), (uint32_t)p->v0, p->vn, k, out_idx, out_sim);
+                           p->rnq.as<float>(), (uint32_t)p->v0, p->vn, k, out_idx, out_sim, dn.word, dn.seq,
+                           dn.ticket);
         CSLAM_HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
@@ -3337,44 +3388,57 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
         float* sim_pin = reinterpret_cast<float*>(static_cast<char*>(p->pin_out.p) + sim_off);
         p->v0 = 0;
         p->vn = p->n;
+        // Completion: the call's final kernel writes this call's number into a pinned word behind its results
+        // (signal_done / k_small_search) and the host polls it - a stream synchronisation costs ~4 us more.
+        // Launch sites that do not signal (two-level selects, GEMM tiles, ...) leave done_taken false and the
+        // call synchronises the stream as before.  CSLAM_SMALL_BEST_POLL=0: always synchronise (A/B).
+        // Polled only for calls with <= 32 KiB of queries: with more (16 x 4096-d: 256 KiB, 80 x 4096-d: 1.3 MB)
+        // the polled call measured 6-12 us SLOWER than the synchronised one (the next call's query copy is
+        // queued on a stream the runtime has not seen idle), profiles/r04_host_call_ab.txt; =2 polls always.
+        static Knob k_poll{"CSLAM_SMALL_BEST_POLL", 1};
+        const bool poll = knob(k_poll) == 2 || (knob(k_poll) != 0 && qbytes <= ((size_t)32 << 10));
+        if (p->small_scratch.p == nullptr) {
+            CSLAM_TRY(p->small_scratch.reserve(256));
+            CSLAM_HIP_TRY(hipMemsetAsync(p->small_scratch.p, 0, 256, p->stream));
+        }
+        uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(p->pin_out.p) + done_off);
+        const uint32_t seq = ++p->small_seq ? p->small_seq : ++p->small_seq;   // never 0
+        __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
+        bool signalled = false;
         if (small_search_applies(p, n_queries, k)) {
-            // A small pool's best match - the reference's per-keyframe call at its own scale - is ONE launch
-            // (k_small_best).  Queries of up to 1 KiB are read by the kernel from the pinned buffer itself
+            // A small pool - the reference's per-keyframe calls at its own scale - is ONE launch
+            // (k_small_search).  Queries of up to 1 KiB are read by the kernel from the pinned buffer itself
             // (no copy operation in front of the launch; larger ones would cross the host link once per
-            // block), and the host polls a word the kernel writes behind its results instead of paying a
-            // stream synchronisation.  CSLAM_SMALL_BEST_Q=0/1 and CSLAM_SMALL_BEST_POLL=0: A/B.
+            // block).  CSLAM_SMALL_BEST_Q=0/1: A/B.
             static Knob k_q{"CSLAM_SMALL_BEST_Q", -1};
-            static Knob k_poll{"CSLAM_SMALL_BEST_POLL", 1};
             const bool from_pin = knob(k_q) < 0 ? qbytes <= 1024 : knob(k_q) != 0;
             if (!from_pin)
                 CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
-            uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(p->pin_out.p) + done_off);
-            const uint32_t seq = ++p->small_seq ? p->small_seq : ++p->small_seq;   // never 0
-            const bool poll = knob(k_poll) != 0;
-            if (poll) __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
             CSLAM_TRY(small_search(p, from_pin ? p->pin_q.as<float>() : p->h_q.as<float>(), p->dim, n_queries, k,
                                    idx_pin, sim_pin, p->stream, poll ? done : nullptr, seq));
-            bool seen = false;
-            if (poll) {
-                // (a kernel that never writes the word - a fault - ends in the synchronisation below, which
-                // reports it)
-                const auto t0 = std::chrono::steady_clock::now();
-                for (int spins = 1; !seen; ++spins) {
-                    seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq;
-                    if (!seen && (spins & 255) == 0 &&
-                        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
-                        break;
-                }
-            }
-            if (!seen) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
-            memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));
-            memcpy(out_sim, sim_pin, obytes * sizeof(float));
-            p->dev_pending = false;
-            return CSLAM_OK;
+            signalled = poll;
+        } else {
+            CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+            p->done_word = poll ? done : nullptr;
+            p->done_taken = false;
+            const int rc = search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, idx_pin, sim_pin, p->stream);
+            p->done_word = nullptr;
+            signalled = p->done_taken;
+            if (rc != CSLAM_OK) return rc;
         }
-        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
-        CSLAM_TRY(search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, idx_pin, sim_pin, p->stream));
-        CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+        bool seen = false;
+        if (signalled) {
+            // (a kernel that never writes the word - a fault - ends in the synchronisation below, which reports it;
+            // long scans: poll for as long as the scan may take)
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 1; !seen; ++spins) {
+                seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == seq;
+                if (!seen && (spins & 255) == 0 &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+                    break;
+            }
+        }
+        if (!seen) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
         memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));
         memcpy(out_sim, sim_pin, obytes * sizeof(float));
         p->dev_pending = false;

@@ -235,3 +235,33 @@ def test_growing_pool_keyframe_by_keyframe(gpu):
     item, sim = p.search_best(D[3])
     assert item == 3
     p.close()
+
+
+@pytest.mark.parametrize("n,d,m,k", [
+    (20000, 128, 1, 1),       # k_scan_dma<best> + k_best_pair, one block: signals without a ticket
+    (20000, 128, 16, 1),      # sixteen blocks: the last one to take a ticket signals
+    (20000, 128, 5, 10),      # k_topk_from_parts<WaveParts>
+    (9000, 512, 40, 1),       # k_scan_mq + k_best_pair
+    (9000, 512, 40, 7),       # k_scan_mq + k_topk_from_parts<PanelParts>
+    (9000, 512, 96, 1),       # two passes: only the last pass's final kernel signals
+    (5000, 64, 3, 200),       # two-level select: no signalling launch site, the call synchronises the stream
+])
+def test_polled_completion_of_the_host_call(gpu, knobs, n, d, m, k):
+    """cslam_pool_search's small calls return when the call's final kernel has written the call's number into a
+    pinned word (signal_done), not after a stream synchronisation.  Call after call with DIFFERENT queries -
+    a stale result or an early return would show - against the oracle, polling forced for every size (=2),
+    default (<= 32 KiB of queries) and off."""
+    rs = np.random.RandomState(n + d + m + k)
+    X = rs.rand(n, d).astype(np.float32) - 0.3
+    p = _pool(X)
+    for setting in ("2", "1", "0"):
+        knobs.set("CSLAM_SMALL_BEST_POLL", setting)
+        for call in range(6):
+            Q = rs.rand(m, d).astype(np.float32) - 0.2
+            Q[0] = X[rs.randint(n)]
+            rows, sims = p.search_batch(Q, k)
+            o_idx, o_sim, o_cnt = oracle_knn.search(X, Q, k)
+            kk = int(o_cnt[0])
+            np.testing.assert_array_equal(rows, o_idx[:, :kk])
+            assert sims.tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
+    p.close()
