@@ -112,6 +112,27 @@ int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_
                                int64_t split_row, int64_t row_hi, hipStream_t st,
                                BestCandidates* out, bool* applied, const float* staged = nullptr,
                                const float* staged_rnq = nullptr);
+// What a best-match scan with dots leaves for the rank select of topk_parts.hpp (search with 2 <= k <= 32): the
+// best composite of every part of the window [row_lo, row_hi) - waves of k_scan_dma (kind 0) or panels / K-split
+// strips of k_scan_mq (kind 1) - and the raw dots of every row.  The caller launches the select itself (the
+// shard: its records kernel, in the same launch).  *applied = false (nothing launched) where that scan does
+// not run for this shape: the caller then takes cslam_pool_search_range_dev.
+struct TopkCandidates {
+    const uint64_t* cand = nullptr;
+    int64_t cand_stride = 0;
+    int n_parts = 0, kind = 0;
+    int64_t wq = 0, wrem = 0;                                   // kind 0: WaveParts
+    int64_t n_main = 0;                                         // kind 1: PanelParts
+    int n_blocks = 0, p_max = 0, nw = 0, ns = 0, n_main_parts = 0;
+    const float* dots = nullptr;
+    int64_t dots_stride = 0;
+    const float* rnx = nullptr;   // 1 / ||x|| of the window's rows
+    const float* rnq = nullptr;   // 1 / ||q|| of the m queries
+    uint32_t row0 = 0;            // pool row of the window's first row
+    int64_t n = 0;                // rows of the window
+};
+int pool_topk_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m, int k,
+                         int64_t row_lo, int64_t row_hi, hipStream_t st, TopkCandidates* out, bool* applied);
 // The multi-tile scan reads its queries from a zero-padded block [16 ceil(m / 16)][padded dim] next to
 // their inverse norms.  A caller that has the queries a step early (the shard: the exchange lands while
 // the previous step is being scanned) stages them on ITS stream into buffers of its own.

@@ -27,6 +27,7 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
+#include "topk_parts.hpp"
 #include "probe_hooks.hpp"
 
 using namespace cslam;
@@ -1420,259 +1421,6 @@ __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __re
     out_sim[j] = -INFINITY;
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_topk_from_parts: exact top-k (2 <= k <= 32) of ONE query per block from what a fused scan left:
-// the best (similarity, row) composite of every PART of the window (cand) and the raw dots of every
-// row.  A part is what one composite covers: a wave's share of the window (k_scan_dma: WaveParts),
-// a panel of the multi-tile scan's main launch or a strip of its K-split launch (k_scan_mq +
-// k_mq_combine: PanelParts).
-//   The k-th best row is at least as good as the k-th best PART maximum (k distinct parts hold k
-//   distinct rows that good), and a part whose maximum is below it holds no row of the top k: the
-//   candidates are the rows of the k best parts - ~k x 112 rows of the 100 000.  Round 2 ran k
-//   block-wide arg-max rounds over every 4096 rows of the pool plus a merge level (14 + 9 us and a
-//   6.4-MB dots read); this is one launch over ~1100 rows, and no serial rounds: selections are
-//   by RANK (composites are unique: #{others greater} is the output position).
-//   A1  every thread takes the best of its part maxima (parts tid, tid + 256, ...); a hardware wave
-//       ranks its 64 thread maxima by their similarity word (64 readlanes) -> the k-th largest is a
-//       lower bound of the k-th best part maximum; T1 = the best of the four bounds.
-//   A2  part maxima >= T1 (a few times k of the ~1000) go to an LDS list with their part number.
-//   A3  rank inside the list: ranks < k are the k best parts, rank k-1 is the bound Tk.
-//   B1  composites of those parts' rows (dot x 1/||x|| x 1/||q||, as every other path; the row
-//       ranges follow from the scan's partition of the window, Parts::range); those >= Tk (k of
-//       them at least, rarely many more) go to the list.
-//   B2  rank inside the list = output position.  A list overflow (> 1024 rows at or above the
-//       bound: an all-zero query over parts of > 64 rows - or > 1024 parts at or above T1: the same
-//       query over a window of many strips) takes k rounds of block arg-max instead.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTopkWavesMaxK = 32;   // (the shard's fused intra + inter search asks for block + nb_best_matches <= 26)
-constexpr int kTopkWavesMax = 1024;  // list entries (and the parts of WaveParts: 4 x CUs at most)
-constexpr int kTopkPartsMax = 65535; // part numbers are kept in 16 bits
-
-// k_scan_dma: the window's n rows split evenly over n_waves (launch_scan_dma)
-struct WaveParts {
-    int64_t wq, wrem;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
-        lo = c * wq + (c < wrem ? c : wrem);
-        cnt = (int)(wq + (c < wrem ? 1 : 0));
-    }
-};
-// k_scan_mq: parts [0, n_main_parts) are the panels of the main launch - number
-// (block * p_max + round) * nw + wave, the strips of a block split evenly over its nw x rounds
-// panels (scan_mq.hip, "Rows are dealt out in whole 16-row strips") - and part n_main_parts + s is
-// strip s of the K-split launch's window [n_main, n) (k_mq_combine)
-struct PanelParts {
-    int64_t n_main, n;
-    int n_blocks, p_max, nw, ns, n_main_parts;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
-        if (c >= n_main_parts) {
-            lo = n_main + ((int64_t)(c - n_main_parts) << 4);
-            const int64_t left = n - lo;
-            cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-            return;
-        }
-        const int wave = c % nw, br = c / nw, rd = br % p_max, bidx = br / p_max;
-        const int64_t S = (n_main + 15) >> 4;
-        const int64_t bq = S / n_blocks, brem = S - bq * n_blocks;
-        const int64_t bs_lo = (int64_t)bidx * bq + (bidx < brem ? bidx : brem);
-        const int bs = (int)(bq + (bidx < brem ? 1 : 0));
-        const int P = (bs + nw * ns - 1) / (nw * ns);
-        lo = 0;
-        cnt = 0;
-        if (bs == 0 || rd >= P) return;
-        const int npan = nw * P, pq = bs / npan, prem = bs - pq * npan;
-        const int q0 = nw * rd + wave, q1 = q0 + 1;
-        lo = (bs_lo + (int64_t)q0 * pq + (q0 < prem ? q0 : prem)) << 4;
-        int64_t hi = (bs_lo + (int64_t)q1 * pq + (q1 < prem ? q1 : prem)) << 4;
-        hi = hi < n_main ? hi : n_main;
-        cnt = hi > lo ? (int)(hi - lo) : 0;
-    }
-};
-
-// (the body: ONE query - its part maxima cq[0..n_parts), its dots dq[0..n), 1/||q|| = rq - by one 256-thread
-// block; results to oi/os[0..k).  Block-uniform control flow; callers that run it for several queries in a row
-// put a barrier between two calls.)
-__device__ inline void signal_done(uint32_t* done, uint32_t seq, uint32_t* ticket);   // (defined in front of k_best_pair)
-
-// k_small_search<true>: part s is strip s of the window (16 rows)
-struct StripParts {
-    int64_t n;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
-        lo = (int64_t)c << 4;
-        const int64_t left = n - lo;
-        cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
-    }
-};
-
-template <class Parts>
-__device__ inline void topk_from_parts_body(const uint64_t* cq, int n_parts, const Parts& parts,
-                                            const float* dq, const float* __restrict__ rnx,
-                                            const float rq, uint32_t row0, int64_t n, int k,
-                                            int32_t* __restrict__ oi, float* __restrict__ os) {
-    __shared__ uint64_t lst[kTopkWavesMax];
-    __shared__ uint16_t lst_w[kTopkWavesMax];
-    __shared__ uint64_t wmax[2][4];
-    __shared__ uint64_t tk_s;
-    __shared__ uint32_t tw[4];
-    __shared__ int64_t w_lo[kTopkWavesMaxK];
-    __shared__ int w_cnt[kTopkWavesMaxK], w_pre[kTopkWavesMaxK + 1];
-    __shared__ int cnt1, cnt2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        cnt1 = 0;
-        cnt2 = 0;
-        tk_s = 0;
-    }
-    // ---- A1: a lower bound of the k-th best part maximum --------------------------------------
-    uint64_t gm = 0;
-    for (int c = tid; c < n_parts; c += 256) {
-        const uint64_t v = cq[c];
-        gm = v > gm ? v : gm;
-    }
-    const uint32_t ghi = (uint32_t)(gm >> 32);   // an empty thread has 0, below every real similarity word
-    int above = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) above += (uint32_t)__builtin_amdgcn_readlane((int)ghi, j) > ghi ? 1 : 0;
-    // the lanes with fewer than k similarity words above theirs hold the k largest: the least of those
-    uint32_t kth = above < k ? ghi : 0xFFFFFFFFu;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t v = (uint32_t)__shfl_xor((int)kth, o, 64);
-        kth = v < kth ? v : kth;
-    }
-    if (lane == 0) tw[wave] = kth;
-    __syncthreads();
-    uint32_t t1 = tw[0];
-#pragma unroll
-    for (int x = 1; x < 4; ++x) t1 = tw[x] > t1 ? tw[x] : t1;
-    // ---- A2: the part maxima at or above the bound ---------------------------------------------
-    for (int c = tid; c < n_parts; c += 256) {
-        const uint64_t v = cq[c];
-        if (v != 0 && (uint32_t)(v >> 32) >= t1) {
-            const int pos = atomicAdd(&cnt1, 1);
-            if (pos < kTopkWavesMax) {
-                lst[pos] = v;
-                lst_w[pos] = (uint16_t)c;
-            }
-        }
-    }
-    __syncthreads();
-    const int s1 = cnt1;
-    const bool every_row = s1 > kTopkWavesMax;   // too many parts that good: every row is a candidate
-    const int nwin = every_row ? 1 : (s1 < k ? s1 : k);
-    // ---- A3: rank -> the k best parts and the bound Tk -----------------------------------------
-    if (every_row) {
-        if (tid == 0) {
-            w_lo[0] = 0;
-            w_cnt[0] = (int)n;
-        }
-    } else {
-        for (int i = tid; i < s1; i += 256) {
-            const uint64_t c = lst[i];
-            int rank = 0;
-            for (int j = 0; j < s1; ++j) rank += lst[j] > c ? 1 : 0;
-            if (rank < k) {
-                int64_t lo;
-                int cnt;
-                parts.range((int)lst_w[i], lo, cnt);
-                w_lo[rank] = lo;
-                w_cnt[rank] = cnt;
-                if (rank == k - 1) tk_s = c;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid <= nwin) {
-        int pre = 0;
-        for (int j = 0; j < tid; ++j) pre += w_cnt[j];
-        w_pre[tid] = pre;
-    }
-    __syncthreads();
-    const int total = w_pre[nwin];
-    const uint64_t tk = tk_s;
-    // window-relative row of candidate number idx: the last winner whose first candidate is <= idx
-    // (nwin <= 32: five steps)
-    auto row_at = [&](int idx) -> int64_t {
-        int j = 0;
-#pragma unroll
-        for (int step = 16; step > 0; step >>= 1)
-            if (j + step < nwin && idx >= w_pre[j + step]) j += step;
-        return w_lo[j] + (idx - w_pre[j]);
-    };
-    auto comp_at = [&](int idx) -> uint64_t {     // composite of candidate number idx
-        const int64_t row = row_at(idx);
-        return make_comp((dq[row] * rnx[row]) * rq, row0 + (uint32_t)row);
-    };
-    int s2 = kTopkWavesMax + 1;
-    if (!every_row) {
-        // ---- B1: the rows of those parts at or above Tk ----------------------------------------
-        // (up to eight candidates per thread with all their loads in flight together: one memory round
-        // trip instead of one per candidate)
-        constexpr int kBatch = 8;
-        for (int base = 0; base < total; base += kBatch * 256) {
-            int64_t row[kBatch];
-            float dv[kBatch], rx[kBatch];
-#pragma unroll
-            for (int e = 0; e < kBatch; ++e) {
-                const int idx = base + e * 256 + tid;
-                row[e] = idx < total ? row_at(idx) : -1;
-            }
-#pragma unroll
-            for (int e = 0; e < kBatch; ++e) {
-                const int64_t r_ = row[e] >= 0 ? row[e] : 0;
-                dv[e] = dq[r_];
-                rx[e] = rnx[r_];
-            }
-#pragma unroll
-            for (int e = 0; e < kBatch; ++e) {
-                const uint64_t c = row[e] >= 0 ? make_comp((dv[e] * rx[e]) * rq, row0 + (uint32_t)row[e]) : 0;
-                if (row[e] >= 0 && c >= tk) {
-                    const int pos = atomicAdd(&cnt2, 1);
-                    if (pos < kTopkWavesMax) lst[pos] = c;
-                }
-            }
-        }
-        __syncthreads();
-        s2 = cnt2;
-    }
-    if (s2 <= kTopkWavesMax) {
-        // ---- B2: rank = output position ---------------------------------------------------------
-        for (int i = tid; i < s2; i += 256) {
-            const uint64_t c = lst[i];
-            int rank = 0;
-            for (int j = 0; j < s2; ++j) rank += lst[j] > c ? 1 : 0;
-            if (rank < k) {
-                oi[rank] = (int32_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFu));
-                os[rank] = ord2f((uint32_t)(c >> 32));
-            }
-        }
-        for (int j = s2 + tid; j < k; j += 256) {   // fewer rows than k
-            oi[j] = -1;
-            os[j] = -INFINITY;
-        }
-        return;
-    }
-    // ---- overflow: k rounds of block arg-max over the candidates, each below the previous winner
-    uint64_t last = ~0ull;
-    for (int rd = 0; rd < k; ++rd) {
-        uint64_t mt = 0;
-        for (int idx = tid; idx < total; idx += 256) {
-            const uint64_t c = comp_at(idx);
-            mt = (c < last && c > mt) ? c : mt;
-        }
-        const uint64_t m = wave_max_u64(mt);
-        if (lane == 0) wmax[rd & 1][wave] = m;
-        __syncthreads();
-        uint64_t win = wmax[rd & 1][0];
-#pragma unroll
-        for (int x = 1; x < 4; ++x) win = wmax[rd & 1][x] > win ? wmax[rd & 1][x] : win;
-        if (tid == 0) {
-            oi[rd] = win ? (int32_t)(0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFu)) : -1;
-            os[rd] = win ? ord2f((uint32_t)(win >> 32)) : -INFINITY;
-        }
-        last = win;   // 0 when nothing is left: the remaining rounds write the empty result
-    }
-}
-
 template <class Parts>
 __global__ __launch_bounds__(256) void k_topk_from_parts(const uint64_t* __restrict__ cand, int64_t cand_stride,
                                                          int n_parts, const Parts parts,
@@ -1845,24 +1593,6 @@ __global__ __launch_bounds__(256) void k_small_search(const float* __restrict__ 
     }
 }
 
-// Completion word of the host-pointer API's small calls (cslam_pool_search): the results sit in pinned host
-// memory and the host polls `done` for the call's number instead of paying a stream synchronisation.  Every
-// block calls this behind its last result store; the LAST block of the launch to get here writes the word.
-__device__ inline void signal_done(uint32_t* done, uint32_t seq, uint32_t* ticket) {
-    if (done == nullptr) return;   // grid-uniform
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = gridDim.x * gridDim.y;
-        bool last = true;
-        if (total > 1) {
-            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
-            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (last) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // final level of search_best: one block per (query, window) reduces the waves' composites.
 // window 1 (blockIdx.y == 1) exists for the split search only.
 __global__ __launch_bounds__(256) void k_best_pair(const uint64_t* __restrict__ cand_a,
@@ -1917,9 +1647,13 @@ struct cslam_pool {
     // ordering between the device-pointer API (caller's stream) and the host-pointer API (the
     // pool's own non-blocking stream): every *_dev call records dev_ev on its stream, the next
     // call on a different stream waits for it first
+    // (round 4: the event is recorded LAZILY - by the first call that needs it, on dev_stream, i.e. behind
+    // everything enqueued there since - so that a loop of *_dev calls on one stream carries no event packet
+    // between its kernels)
     hipEvent_t dev_ev = nullptr;
     hipStream_t dev_stream = nullptr;
     bool dev_pending = false;
+    bool dev_deferred = false;
     // ... and the sharded step's append, which runs on the exchange stream while scans of earlier
     // steps are still marked on the compute stream: an event of its own, so that neither mark
     // hides the other
@@ -1938,10 +1672,20 @@ namespace {
 thread_local const cslam_pool* tls_shard_scope = nullptr;
 inline bool shard_scope(const cslam_pool* p) { return tls_shard_scope == p; }
 
+// the event behind the last device-API work, recorded now if that was put off (mark_dev)
+int dev_event_now(cslam_pool* p) {
+    if (p->dev_pending && p->dev_deferred) {
+        CSLAM_HIP_TRY(hipEventRecord(p->dev_ev, p->dev_stream));
+        p->dev_deferred = false;
+    }
+    return CSLAM_OK;
+}
 // make `st` wait for the last device-API work enqueued on another stream
 int order_after_dev(cslam_pool* p, hipStream_t st) {
-    if (p->dev_pending && p->dev_stream != st)
+    if (p->dev_pending && p->dev_stream != st) {
+        CSLAM_TRY(dev_event_now(p));
         CSLAM_HIP_TRY(hipStreamWaitEvent(st, p->dev_ev, 0));
+    }
     if (p->app_pending && p->app_stream != st && !shard_scope(p)) {
         // the append was issued a whole step ahead of the scan that needs it: normally it is
         // complete, and then the stream is spared the cross-stream barrier packet (~10 us in
@@ -1954,8 +1698,19 @@ int order_after_dev(cslam_pool* p, hipStream_t st) {
     return CSLAM_OK;
 }
 // remember that device-API work is in flight on `st`
+// (the event itself is recorded by whoever needs it first - dev_event_now - unless the work moves to another
+// stream: an event packet behind every search cost the loop of one-stream callers ~1-2 us per call, measured
+// in profiles/r04_dev_event_ab.txt; CSLAM_DEV_EVENT=1 records at once, A/B)
+bool dev_event_eager();   // (the knob, defined with the other knobs below)
 int mark_dev(cslam_pool* p, hipStream_t st) {
-    CSLAM_HIP_TRY(hipEventRecord(p->dev_ev, st));
+    if (p->dev_pending && p->dev_deferred && p->dev_stream != st)
+        CSLAM_TRY(dev_event_now(p));   // earlier work on another stream: its event before the mark moves on
+    if (dev_event_eager()) {
+        CSLAM_HIP_TRY(hipEventRecord(p->dev_ev, st));
+        p->dev_deferred = false;
+    } else {
+        p->dev_deferred = true;
+    }
     p->dev_stream = st;
     p->dev_pending = true;
     return CSLAM_OK;
@@ -2060,6 +1815,10 @@ int knob(Knob& k) {
         k.generation.store(g, std::memory_order_release);
     }
     return k.value.load(std::memory_order_relaxed);
+}
+bool dev_event_eager() {   // CSLAM_DEV_EVENT=1: record the device-API event behind every *_dev call (mark_dev)
+    static Knob k_eager{"CSLAM_DEV_EVENT", 0};
+    return knob(k_eager) != 0;
 }
 
 // small pool (fewer strips than CUs) with long descriptors: k_scan_dma_ks (K split over the waves
@@ -3136,6 +2895,7 @@ int cslam_pool_create(int dim, int64_t capacity_hint, int device_id, cslam_pool_
 int cslam_pool_destroy(cslam_pool_t* p) {
     if (!p) return CSLAM_OK;
     (void)hipSetDevice(p->device);
+    (void)dev_event_now(p);
     if (p->dev_pending) (void)hipEventSynchronize(p->dev_ev);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->app_pending) (void)hipEventSynchronize(p->app_ev);
@@ -3240,6 +3000,7 @@ int cslam_pool_read_rows(const cslam_pool_t* p, int64_t first, int64_t n, float*
                     (long long)first, (long long)n, (long long)(p ? p->cap : 0));
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_TRY(dev_event_now(const_cast<cslam_pool_t*>(p)));
     if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
     if (p->app_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->app_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
@@ -3254,6 +3015,7 @@ int cslam_pool_read_inv_norms(const cslam_pool_t* p, int64_t first, int64_t n, f
         return fail(CSLAM_E_INVALID, "pool_read_inv_norms: bad range");
     if (n == 0) return CSLAM_OK;
     CSLAM_HIP_TRY(hipSetDevice(p->device));
+    CSLAM_TRY(dev_event_now(const_cast<cslam_pool_t*>(p)));
     if (p->dev_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->dev_ev));
     if (p->app_pending) CSLAM_HIP_TRY(hipEventSynchronize(p->app_ev));
     CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
@@ -3600,6 +3362,69 @@ int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_
     CSLAM_TRY(best_scan_candidates(p, queries_dev, query_stride, m, split_row, &out->stride, &out->n, st));
     out->a = p->cand_a.as<uint64_t>();
     out->c = p->cand_c.as<uint64_t>();
+    *applied = true;
+    return mark_dev(p, st);
+}
+
+// the scan half of search with 2 <= k <= 32 (search_dev_impl's two fused top-k branches, stopped in front of
+// k_topk_from_parts): see TopkCandidates in common.hpp
+int pool_topk_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m, int k,
+                         int64_t row_lo, int64_t row_hi, hipStream_t st, TopkCandidates* out, bool* applied) {
+    *applied = false;
+    if (!p || !out || m < 1 || k < 2 || k > kTopkWavesMaxK || !queries_dev || query_stride < p->dim ||
+        row_lo < 0 || row_hi > p->n || row_hi <= row_lo)
+        return CSLAM_OK;
+    static Knob k_tw{"CSLAM_TOPK_WAVES", 1};
+    if (knob(k_tw) == 0) return CSLAM_OK;
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    p->v0 = row_lo;
+    p->vn = row_hi - row_lo;
+    const int64_t sims_stride = (p->vn + 63) / 64 * 64;
+    out->rnx = p->inv_norm + p->v0;
+    out->row0 = (uint32_t)p->v0;
+    out->n = p->vn;
+    out->dots_stride = sims_stride;
+    if (m <= 16) {
+        if (!dma_scan_applies(p) || ks_scan_applies(p, m) || (int64_t)p->cus * 4 > kTopkWavesMax) return CSLAM_OK;
+        CSLAM_TRY(order_after_dev(p, st));
+        CSLAM_TRY(p->sims.reserve((size_t)16 * sims_stride * sizeof(float)));
+        int64_t cstride = 0, n_cand = 0;
+        CSLAM_TRY(best_scan_candidates(p, queries_dev, query_stride, m, -1, &cstride, &n_cand, st,
+                                       p->sims.as<float>(), sims_stride));
+        out->kind = 0;
+        out->cand = p->cand_a.as<uint64_t>();
+        out->cand_stride = cstride;
+        out->n_parts = (int)n_cand;
+        out->wq = p->vn / n_cand;
+        out->wrem = p->vn % n_cand;
+        out->dots = p->sims.as<float>();
+        out->rnq = p->rnq.as<float>();
+        *applied = true;
+        return mark_dev(p, st);
+    }
+    if (!mq_scan_applies(p, m) || mq_pass_queries(m) != m) return CSLAM_OK;   // one k_scan_mq pass: 17..80 queries
+    const MqPlan g = mq_plan(p, m);
+    if (g.n_cand > kTopkPartsMax) return CSLAM_OK;
+    CSLAM_TRY(order_after_dev(p, st));
+    CSLAM_TRY(p->qstage.reserve((size_t)(kQueryChunk + 128) * p->dp * sizeof(float)));
+    CSLAM_TRY(p->rnq.reserve((size_t)(kQueryChunk + kMaxQueriesPerPass) * sizeof(float)));
+    CSLAM_TRY(p->sims.reserve((size_t)16 * mq_max_tiles() * sims_stride * sizeof(float)));
+    const int64_t cstride = (g.n_cand + 63) / 64 * 64;
+    CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
+    CSLAM_TRY(mq_pass(p, queries_dev, query_stride, m, p->rnq.as<float>(), p->sims.as<float>(), sims_stride, true,
+                      p->cand_a.as<uint64_t>(), cstride, -1, nullptr, g, st));
+    out->kind = 1;
+    out->cand = p->cand_a.as<uint64_t>();
+    out->cand_stride = cstride;
+    out->n_parts = (int)g.n_cand;
+    out->n_main = g.n_main;
+    out->n_blocks = g.n_blocks;
+    out->p_max = g.p_max;
+    out->nw = g.waves;
+    out->ns = mq_panel_strips(g.tiles, g.waves);
+    out->n_main_parts = g.n_blocks * g.p_max * g.waves;
+    out->dots = p->sims.as<float>();
+    out->rnq = p->rnq.as<float>();
     *applied = true;
     return mark_dev(p, st);
 }

@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "composite.hpp"
+#include "topk_parts.hpp"
 
 using namespace cslam;
 
@@ -54,23 +55,17 @@ __global__ __launch_bounds__(256) void k_pack_block(const float* __restrict__ sr
 // else : idx_a/sim_a = best in [0, n0), idx_c/sim_c = best in [n0, n0 + b).
 // Record slots 3i (received descriptor vs old rows), 3i+1 (vs new rows, on the peer's behalf),
 // 3i+2 (own descriptor: intra-robot match); robot0_id = -1 marks an empty slot.
+// The record slots of ONE gathered descriptor i (one thread): see k_make_records.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_make_records(
-    int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
-    int32_t* __restrict__ kf_of_row, int b_own, double thr, const int32_t* __restrict__ topk_idx,
-    const float* __restrict__ topk_sim, int K, int k_local, int min_inbetween,
-    const int32_t* __restrict__ idx_a, const float* __restrict__ sim_a,
-    const int32_t* __restrict__ idx_c, const float* __restrict__ sim_c,
+__device__ inline void make_records_one(
+    int i, int me, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
+    const int32_t* kf_of_row, double thr, const int32_t* topk_idx, const float* topk_sim, int K, int k_local,
+    int min_inbetween, const int32_t* idx_a, const float* sim_a, const int32_t* idx_c, const float* sim_c,
     cslam_match_record_t* __restrict__ recs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    // keyframe id of the pool rows appended by this step: rows >= n0 are looked up in the own
-    // meta block below (their table entries are written here, for the steps to come)
     const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
-    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
     auto kf_at = [&](int32_t row) {
         return row >= n0 ? (int32_t)own_meta[1 + (row - n0)] : kf_of_row[row];
     };
-    if (i >= nb_robots * b_max) return;
     const int s = i / b_max, j = i % b_max;
     const int64_t* meta = all_meta + (int64_t)s * (1 + b_max);
     cslam_match_record_t none;
@@ -147,6 +142,46 @@ __global__ __launch_bounds__(256) void k_make_records(
     recs[3 * (int64_t)i + 0] = r0;
     recs[3 * (int64_t)i + 1] = r1;
     recs[3 * (int64_t)i + 2] = r2;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_make_records(
+    int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
+    int32_t* __restrict__ kf_of_row, int b_own, double thr, const int32_t* __restrict__ topk_idx,
+    const float* __restrict__ topk_sim, int K, int k_local, int min_inbetween,
+    const int32_t* __restrict__ idx_a, const float* __restrict__ sim_a,
+    const int32_t* __restrict__ idx_c, const float* __restrict__ sim_c,
+    cslam_match_record_t* __restrict__ recs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    // keyframe id of the pool rows appended by this step: rows >= n0 are looked up in the own
+    // meta block (their table entries are written here, for the steps to come)
+    const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
+    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
+    if (i >= nb_robots * b_max) return;
+    make_records_one<FUSED>(i, me, b_max, all_meta, n0, kf_of_row, thr, topk_idx, topk_sim, K, k_local, min_inbetween,
+                            idx_a, sim_a, idx_c, sim_c, recs);
+}
+
+// Fused intra + inter search, rank select and records in ONE launch behind the scan (round 4): block i runs the
+// rank select of topk_parts.hpp for gathered descriptor i over what the best-match scan with dots left
+// (pool_topk_candidates) and its first thread goes on to the descriptor's record slots - instead of
+// k_topk_from_parts + k_make_records<true> (one kernel boundary of ~6 us and a 4-us launch less per step).
+template <class Parts>
+__global__ __launch_bounds__(256) void k_topk_records(
+    const uint64_t* cand, int64_t cand_stride, int n_parts, const Parts parts, const float* dots,
+    int64_t dots_stride, const float* __restrict__ rnx, const float* __restrict__ rnq, uint32_t row0, int64_t n,
+    int me, int b_max, const int64_t* __restrict__ all_meta, int64_t n0, int32_t* kf_of_row, int b_own, double thr,
+    int32_t* topk_idx, float* topk_sim, int K, int k_local, int min_inbetween,
+    cslam_match_record_t* __restrict__ recs) {
+    const int i = blockIdx.x;
+    topk_from_parts_body(cand + (int64_t)i * cand_stride, n_parts, parts, dots + (int64_t)i * dots_stride, rnx, rnq[i],
+                         row0, n, K, topk_idx + (int64_t)i * K, topk_sim + (int64_t)i * K);
+    __syncthreads();   // the block's list is complete and visible to its first thread
+    if (threadIdx.x != 0) return;
+    const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
+    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
+    make_records_one<true>(i, me, b_max, all_meta, n0, kf_of_row, thr, topk_idx, topk_sim, K, k_local, min_inbetween,
+                           nullptr, nullptr, nullptr, nullptr, recs);
 }
 
 // Split best-match mode, final level and records in ONE launch behind the scan: block i reduces
@@ -547,11 +582,33 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     } else if (sh->fused) {
         // ONE scan of rows [0, n0 + b): the sorted top-K (K > b) of every gathered descriptor
         // holds both its best older row and its best row of the new block
-        CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, M, sh->K, 0, hi, s.topk_idx,
-                                              s.topk_sim, st));
-        hipLaunchKernelGGL((k_make_records<true>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
-                           n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
-                           sh->min_inbetween, nullptr, nullptr, nullptr, nullptr, my_recs);
+        // (round 4) the scan leaves the parts' composites and the dots; rank select AND records in one launch
+        // behind it.  Where that scan does not run for this shape (tiny pools, K > 32, several passes):
+        // the pool's own search, then the records.  CSLAM_SHARD_FUSE_TOPK=0: always the latter (A/B).
+        static const bool fuse_env = !(getenv("CSLAM_SHARD_FUSE_TOPK") && atoi(getenv("CSLAM_SHARD_FUSE_TOPK")) == 0);
+        TopkCandidates tc;
+        bool applied = false;
+        if (fuse_env)
+            CSLAM_TRY(pool_topk_candidates(sh->pool, s.all_rows, dim, M, sh->K, 0, hi, st, &tc, &applied));
+        if (applied && tc.kind == 0) {
+            const WaveParts parts{tc.wq, tc.wrem};
+            hipLaunchKernelGGL((k_topk_records<WaveParts>), dim3(M), dim3(256), 0, st, tc.cand, tc.cand_stride,
+                               tc.n_parts, parts, tc.dots, tc.dots_stride, tc.rnx, tc.rnq, tc.row0, tc.n, me, bm,
+                               s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K,
+                               sh->k_local, sh->min_inbetween, my_recs);
+        } else if (applied) {
+            const PanelParts parts{tc.n_main, tc.n, tc.n_blocks, tc.p_max, tc.nw, tc.ns, tc.n_main_parts};
+            hipLaunchKernelGGL((k_topk_records<PanelParts>), dim3(M), dim3(256), 0, st, tc.cand, tc.cand_stride,
+                               tc.n_parts, parts, tc.dots, tc.dots_stride, tc.rnx, tc.rnq, tc.row0, tc.n, me, bm,
+                               s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K,
+                               sh->k_local, sh->min_inbetween, my_recs);
+        } else {
+            CSLAM_TRY(cslam_pool_search_range_dev(sh->pool, s.all_rows, dim, M, sh->K, 0, hi, s.topk_idx,
+                                                  s.topk_sim, st));
+            hipLaunchKernelGGL((k_make_records<true>), dim3(gm), dim3(256), 0, st, me, R, bm, s.all_meta,
+                               n0, sh->kf_of_row, s.b, sh->thr, s.topk_idx, s.topk_sim, sh->K, sh->k_local,
+                               sh->min_inbetween, nullptr, nullptr, nullptr, nullptr, my_recs);
+        }
     } else {
         // bulk blocks: best old row of every FOREIGN descriptor (the own block is skipped: two
         // calls around it), best new row through the row-range search
