@@ -1675,8 +1675,13 @@ inline bool shard_scope(const cslam_pool* p) { return tls_shard_scope == p; }
 // the event behind the last device-API work, recorded now if that was put off (mark_dev)
 int dev_event_now(cslam_pool* p) {
     if (p->dev_pending && p->dev_deferred) {
-        CSLAM_HIP_TRY(hipEventRecord(p->dev_ev, p->dev_stream));
         p->dev_deferred = false;
+        if (hipEventRecord(p->dev_ev, p->dev_stream) != hipSuccess) {
+            // the caller's stream is gone (destroyed since): whatever ran on it is ordered by the device
+            (void)hipGetLastError();
+            CSLAM_HIP_TRY(hipDeviceSynchronize());
+            p->dev_pending = false;
+        }
     }
     return CSLAM_OK;
 }

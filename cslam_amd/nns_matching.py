@@ -134,11 +134,15 @@ class NearestNeighborsMatching(object):
         vector: 1-D float array (any float dtype; stored as fp32).
         item:   whatever the caller wants back from `search` for this row (a keyframe id).
         """
-        vector = _to_numpy_f32(vector).reshape(-1)
+        if not (type(vector) is np.ndarray and vector.dtype == np.float32 and vector.flags["C_CONTIGUOUS"]):
+            vector = _to_numpy_f32(vector)
         if self._pool is None:
-            self._create(len(vector))
-        row = vector.reshape(1, self.dim)
-        _lib.check(self._lib.cslam_pool_add(self._pool, _lib.ptr(row), 1))
+            self._create(vector.size)
+        if vector.size != self.dim:
+            raise ValueError(f"descriptor size {vector.size} != pool dim {self.dim}")
+        rc = self._lib.cslam_pool_add(self._pool, vector.ctypes.data, 1)
+        if rc != 0:
+            _lib.check(rc)
         self.items[self.n] = item
         self.n += 1
 

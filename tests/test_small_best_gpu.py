@@ -265,3 +265,40 @@ def test_polled_completion_of_the_host_call(gpu, knobs, n, d, m, k):
             np.testing.assert_array_equal(rows, o_idx[:, :kk])
             assert sims.tobytes() == o_sim[:, :kk].astype(np.float32).tobytes()
     p.close()
+
+
+def test_device_calls_on_several_streams_stay_ordered(gpu):
+    """The event that orders device-pointer calls against calls on OTHER streams is recorded lazily (round 4: by
+    the first call that needs it, on the stream the work went to).  Searches on two caller streams and the
+    host-pointer API alternate on one pool - they share its candidate / dots buffers - and every result is the
+    oracle's."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(5)
+    n, d = 30000, 512
+    X = rs.rand(n, d).astype(np.float32) - 0.3
+    p = _pool(X)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rnd in range(4):
+        want, got = [], []
+        for m, k, stream in ((40, 1, sa), (16, 10, sb), (80, 5, sa), (3, 1, sb)):
+            Q = rs.rand(m, d).astype(np.float32) - 0.2
+            with torch.cuda.stream(stream):
+                q = torch.from_numpy(Q).cuda()
+                idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+                sim = torch.empty((m, k), dtype=torch.float32, device="cuda")
+                assert gpu.cslam_pool_search_dev(p.handle, ctypes.c_void_p(q.data_ptr()), d, m, k,
+                                                 ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()),
+                                                 ctypes.c_void_p(stream.cuda_stream)) == 0
+            want.append(oracle_knn.search(X, Q, k))
+            got.append((idx, sim, q))
+            if rnd % 2 == 0:       # a host-pointer call right behind it (the pool's own stream)
+                Qh = rs.rand(2, d).astype(np.float32)
+                rows, sims = p.search_batch(Qh, 3)
+                o_idx, o_sim, _ = oracle_knn.search(X, Qh, 3)
+                np.testing.assert_array_equal(rows, o_idx)
+                assert sims.tobytes() == o_sim.tobytes()
+        torch.cuda.synchronize()
+        for (o_idx, o_sim, _), (idx, sim, _) in zip(want, got):
+            np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+            assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
+    p.close()
