@@ -465,3 +465,18 @@ def test_loopback_communicator_step_matches_oracle(gpu):
     assert sum(len(g) for g in got) > 20
     assert pool.n == kf
     sh.close(); cd.close(); cr.close(); pool.close()
+
+
+def test_fused_step_without_the_one_launch_rank_select(gpu):
+    """Round 4 runs the fused step's rank select and records in ONE launch behind the scan (k_topk_records over
+    pool_topk_candidates).  The path it replaced - the pool's own search + k_make_records<true>, still taken for
+    shapes that scan does not cover - stays covered: the fused tests again with CSLAM_SHARD_FUSE_TOPK=0 (read once
+    per process, hence a child process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSLAM_SHARD_FUSE_TOPK="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "tests/test_shard_gpu.py::test_device_shard_matches_reference_semantics"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "2 passed" in out.stdout, out.stdout[-500:]
