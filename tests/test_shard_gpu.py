@@ -292,10 +292,16 @@ def test_pipelined_keyframe_table_growth(gpu):
     sh.close(); cd.close(); pool.close()
 
 
-@pytest.mark.parametrize("R,b,n,dim", [(8, 10, 20000, 128),    # five query tiles, 1250 strips: 157 blocks, staged at publish time
-                                       (3, 10, 25000, 256),    # two tiles, packed because the shard calls
-                                       (8, 10, 9000, 128)])    # fewer strips than waves: no CUs to spare, staged by the scan
-def test_sharded_step_on_a_mid_size_pool_matches_the_oracle(gpu, R, b, n, dim):
+@pytest.mark.parametrize("R,b,n,dim,nb", [
+    (8, 10, 20000, 128, 0),    # five query tiles, 1250 strips: 157 blocks, staged at publish time
+    (3, 10, 25000, 256, 0),    # two tiles, packed because the shard calls
+    (8, 10, 9000, 128, 0),     # fewer strips than waves: no CUs to spare, staged by the scan
+    # with intra-robot matching (round 4: k_topk_records behind pool_topk_candidates, K = b + 10 = 20 / 18)
+    (8, 10, 20000, 128, 10),   # 80 descriptors: one k_scan_mq pass, panels + K-split strips as parts
+    (8, 10, 70000, 128, 10),   # ... main launch + tail
+    (2, 8, 25000, 256, 10),    # 16 descriptors: k_scan_dma<best+dots>, the waves as parts
+])
+def test_sharded_step_on_a_mid_size_pool_matches_the_oracle(gpu, R, b, n, dim, nb):
     """The cfg4 step on a pool of tens of thousands of rows: k_scan_mq runs on just enough blocks for the
     same strips per wave and the gathered block is staged for it at publish time, on the exchange stream
     (csrc/shard.hip).  Robot 0 of R over the loopback communicator (every slot of the
@@ -311,7 +317,7 @@ def test_sharded_step_on_a_mid_size_pool_matches_the_oracle(gpu, R, b, n, dim):
     pool = NearestNeighborsMatching(dim=dim, capacity_hint=n + steps * b)
     pool.add_items(base, [700000 + i for i in range(n)])
     cd = LoopbackComm(me, R, 0)
-    sh = DeviceShard(pool, me, R, b, 0.0, cd, cd, nb_best_matches=0)
+    sh = DeviceShard(pool, me, R, b, 0.0, cd, cd, nb_best_matches=nb, intra_min_inbetween=10)
     blocks = []
     for t in range(steps):
         x = rs.rand(b, dim).astype(np.float32)
