@@ -643,6 +643,9 @@ def extras(torch, L, _lib, pool, dev, g, stream, N, D, X):
         tq = timed(torch.rand((mq, D), device=dev, generator=g), 1, 30)
         out[f"search_{mq}queries_ms"] = tq * 1e3
         out[f"search_{mq}queries_candidates_per_s"] = mq / tq
+    # search with k > 1 at 80 queries (the sharded step's fused intra + inter search, K = block + nb_best_matches):
+    # k_scan_mq<best> with dots + k_topk_from_parts since round 4
+    out["search_80queries_k26_ms"] = timed(torch.rand((80, D), device=dev, generator=g), 26, 30) * 1e3
     t = timed(q1024, 1, 3)
     out["bulk_1024queries_ms"] = t * 1e3
     out["bulk_1024queries_candidates_per_s"] = 1024 / t

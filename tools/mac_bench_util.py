@@ -180,7 +180,17 @@ def cfg1_bench():
             t0 = time.perf_counter()
             sel = l.select_candidates(100, {0: True, 1: True})
             t_sel = time.perf_counter() - t0
-        out = {"cfg1_match_phase_s": t_match, "cfg1_searches": 2000, "cfg1_candidates": n_matches,
+        # the two per-keyframe calls by themselves, on the final 1000-row pool (lcsm.py:49 and :85)
+        t0 = time.perf_counter()
+        for kf in range(500):
+            l.local_nnsm.search_best(desc[1, kf])
+        t_best = (time.perf_counter() - t0) / 500
+        t0 = time.perf_counter()
+        for kf in range(500):
+            l.local_nnsm.search(desc[1, kf], 10)
+        t_k10 = (time.perf_counter() - t0) / 500
+        out = {"cfg1_search_best_us_per_call": t_best * 1e6, "cfg1_search_k10_us_per_call": t_k10 * 1e6,
+               "cfg1_match_phase_s": t_match, "cfg1_searches": 2000, "cfg1_candidates": n_matches,
                "cfg1_candidates_per_s": n_matches / t_match, "cfg1_select_candidates_ms": t_sel * 1e3,
                "cfg1_selected": len(sel),
                "cfg1_reference_cpu_8cores": "match phase 1.46 s, select_candidates(100) 1.10 s (BASELINE.md)"}
