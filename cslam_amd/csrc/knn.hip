@@ -1413,6 +1413,16 @@ __global__ __launch_bounds__(256) void k_emit_sorted(const uint64_t* __restrict_
     }
 }
 
+// queries of a small host-pointer call: pinned bounce buffer (device-visible host memory) -> HBM by a kernel - a
+// copy OPERATION costs ~8 us of fixed latency in the stream, this launch ~3 (CSLAM_HOST_Q_COPY=1: hipMemcpyAsync)
+__global__ __launch_bounds__(256) void k_copy_f4(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4,
+                                                 const float* __restrict__ src_tail, float* __restrict__ dst_tail,
+                                                 int n_tail) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = i0; i < n4; i += stride) dst[i] = src[i];
+    if (i0 < n_tail) dst_tail[i0] = src_tail[i0];
+}
+
 __global__ __launch_bounds__(256) void k_fill_empty(int64_t total, int32_t* __restrict__ out_idx,
                                                     float* __restrict__ out_sim) {
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -3127,6 +3137,25 @@ int cslam_pool_similarities_dev(cslam_pool_t* p, const float* queries_dev, int64
     return mark_dev(p, st);
 }
 
+namespace {
+// (both buffers come from hipHostMalloc / hipMalloc: 16-byte aligned)
+int pinned_queries_to_device(cslam_pool* p, size_t qbytes) {
+    static Knob k_copy{"CSLAM_HOST_Q_COPY", 0};
+    if (knob(k_copy) != 0) {
+        CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+        return CSLAM_OK;
+    }
+    const int64_t n4 = (int64_t)(qbytes / 16);
+    const int n_tail = (int)((qbytes % 16) / 4);
+    int64_t blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    hipLaunchKernelGGL(k_copy_f4, dim3((unsigned)blocks), dim3(256), 0, p->stream, p->pin_q.as<f32x4>(),
+                       p->h_q.as<f32x4>(), n4, p->pin_q.as<float>() + n4 * 4, p->h_q.as<float>() + n4 * 4, n_tail);
+    CSLAM_HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+}  // namespace
+
 int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int k,
                       int32_t* out_idx, float* out_sim, int32_t* out_count) {
     if (!p || n_queries < 0 || k < 0 || (n_queries > 0 && !queries) ||
@@ -3159,11 +3188,15 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
         // (signal_done / k_small_search) and the host polls it - a stream synchronisation costs ~4 us more.
         // Launch sites that do not signal (two-level selects, GEMM tiles, ...) leave done_taken false and the
         // call synchronises the stream as before.  CSLAM_SMALL_BEST_POLL=0: always synchronise (A/B).
-        // Polled only for calls with <= 32 KiB of queries: with more (16 x 4096-d: 256 KiB, 80 x 4096-d: 1.3 MB)
-        // the polled call measured 6-12 us SLOWER than the synchronised one (the next call's query copy is
-        // queued on a stream the runtime has not seen idle), profiles/r04_host_call_ab.txt; =2 polls always.
+        // Polled up to 512 KiB of queries (=2: always, =0: never).  With the queries moved by hipMemcpyAsync
+        // (CSLAM_HOST_Q_COPY=1, rounds 1-3) polling paid only up to 32 KiB: the next call's copy operation, queued
+        // on a stream the runtime has not seen idle, made 16 x 4096-d calls 6 us and 80 x 4096-d calls 12 us
+        // SLOWER; with the copy kernel (pinned_queries_to_device) the polled call wins or ties at every size
+        // measured (16 x 4096-d: 276.5 -> 268.9 us; 80 x 4096-d: +0.5 %, hence the bound) - profiles/r04_host_call_ab_3.txt
         static Knob k_poll{"CSLAM_SMALL_BEST_POLL", 1};
-        const bool poll = knob(k_poll) == 2 || (knob(k_poll) != 0 && qbytes <= ((size_t)32 << 10));
+        static Knob k_qcopy{"CSLAM_HOST_Q_COPY", 0};
+        const size_t poll_max = knob(k_qcopy) != 0 ? ((size_t)32 << 10) : ((size_t)512 << 10);
+        const bool poll = knob(k_poll) == 2 || (knob(k_poll) != 0 && qbytes <= poll_max);
         if (p->small_scratch.p == nullptr) {
             CSLAM_TRY(p->small_scratch.reserve(256));
             CSLAM_HIP_TRY(hipMemsetAsync(p->small_scratch.p, 0, 256, p->stream));
@@ -3180,12 +3213,12 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
             static Knob k_q{"CSLAM_SMALL_BEST_Q", -1};
             const bool from_pin = knob(k_q) < 0 ? qbytes <= 1024 : knob(k_q) != 0;
             if (!from_pin)
-                CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+                CSLAM_TRY(pinned_queries_to_device(p, qbytes));
             CSLAM_TRY(small_search(p, from_pin ? p->pin_q.as<float>() : p->h_q.as<float>(), p->dim, n_queries, k,
                                    idx_pin, sim_pin, p->stream, poll ? done : nullptr, seq));
             signalled = poll;
         } else {
-            CSLAM_HIP_TRY(hipMemcpyAsync(p->h_q.p, p->pin_q.p, qbytes, hipMemcpyHostToDevice, p->stream));
+            CSLAM_TRY(pinned_queries_to_device(p, qbytes));
             p->done_word = poll ? done : nullptr;
             p->done_taken = false;
             const int rc = search_dev_impl(p, p->h_q.as<float>(), p->dim, n_queries, k, idx_pin, sim_pin, p->stream);

@@ -245,18 +245,22 @@ def test_growing_pool_keyframe_by_keyframe(gpu):
     (9000, 512, 40, 7),       # k_scan_mq + k_topk_from_parts<PanelParts>
     (9000, 512, 96, 1),       # two passes: only the last pass's final kernel signals
     (5000, 64, 3, 200),       # two-level select: no signalling launch site, the call synchronises the stream
+    (5000, 33, 9, 1),         # 1188 B of queries: the copy kernel's float4 body + a one-float tail
+    (5000, 30, 7, 3),         # 840 B: a two-float tail
+    (20000, 4096, 16, 1),     # 256 KiB of queries: polled since the queries travel by the copy kernel
 ])
 def test_polled_completion_of_the_host_call(gpu, knobs, n, d, m, k):
     """cslam_pool_search's small calls return when the call's final kernel has written the call's number into a
     pinned word (signal_done), not after a stream synchronisation.  Call after call with DIFFERENT queries -
     a stale result or an early return would show - against the oracle, polling forced for every size (=2),
-    default (<= 32 KiB of queries) and off."""
+    default (<= 512 KiB of queries) and off; queries moved by the copy kernel and by hipMemcpyAsync."""
     rs = np.random.RandomState(n + d + m + k)
     X = rs.rand(n, d).astype(np.float32) - 0.3
     p = _pool(X)
-    for setting in ("2", "1", "0"):
+    for setting, qcopy in (("2", "0"), ("1", "0"), ("0", "0"), ("2", "1"), ("1", "1")):
         knobs.set("CSLAM_SMALL_BEST_POLL", setting)
-        for call in range(6):
+        knobs.set("CSLAM_HOST_Q_COPY", qcopy)      # 1: hipMemcpyAsync instead of the copy kernel
+        for call in range(4):
             Q = rs.rand(m, d).astype(np.float32) - 0.2
             Q[0] = X[rs.randint(n)]
             rows, sims = p.search_batch(Q, k)
