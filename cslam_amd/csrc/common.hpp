@@ -138,7 +138,9 @@ int pool_topk_candidates(cslam_pool_t* p, const float* queries_dev, int64_t quer
 // the previous step is being scanned) stages them on ITS stream into buffers of its own.
 int pool_mq_free_cus(const cslam_pool_t* p, int m, int64_t rows);   // CUs that scan leaves to other streams
 int64_t pool_staged_floats(const cslam_pool_t* p, int m);   // floats of the staged block (norms: 16 ceil(m / 16))
+// (group_rows > 0: row w sits at queries_dev + (w / group_rows) * group_stride + (w % group_rows) * query_stride)
 int pool_stage_queries_on(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
-                          float* staged, float* staged_rnq, hipStream_t st);
+                          float* staged, float* staged_rnq, hipStream_t st, int group_rows = 0,
+                          int64_t group_stride = 0);
 
 }  // namespace cslam

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
                                                        int mq_pad, int dp,
                                                        float* __restrict__ stage,
                                                        float* __restrict__ rnq, int vec_ok,
-                                                       int64_t copy_stride) {
+                                                       int64_t copy_stride, int group_rows,
+                                                       int64_t group_stride) {
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     if (w >= mq_pad) return;
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(256) void k_stage_queries(const float* __restrict__
         if (tid == 0 && blockIdx.y == 0) rnq[w] = 0.0f;
         return;
     }
-    const float* s = q + (int64_t)w * q_stride;
+    // (group_rows > 0: the rows come in groups of that many, group_stride floats apart - the sharded step's
+    // exchange buffer, one part per rank: rows, then a header - and are staged straight from there)
+    const float* s = group_rows > 0 ? q + (int64_t)(w / group_rows) * group_stride + (int64_t)(w % group_rows) * q_stride
+                                    : q + (int64_t)w * q_stride;
     for (int k = tid * 4; k < dp; k += 1024) {
         f32x4 v;
         if (vec_ok && k + 3 < dim)
@@ -2284,7 +2288,7 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
     if (staged == nullptr) {
         const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim, m,
-                           mq_pad, p->dp, p->qstage.as<float>(), rnq, vec_ok, (int64_t)0);
+                           mq_pad, p->dp, p->qstage.as<float>(), rnq, vec_ok, (int64_t)0, 0, (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
     }
     MqArgs a{};
@@ -2388,7 +2392,7 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, q_dev, q_stride, p->dim,
                            m, mq_pad, p->dp, p->qstage.as<float>(), p->rnq.as<float>(), vec_ok,
-                           (int64_t)0);
+                           (int64_t)0, 0, (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
         bool prof = prof_take(p);
         if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
@@ -2484,7 +2488,7 @@ int compute_dots(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, flo
         }
         hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, p->q_copies), dim3(256), 0, st, qsrc,
                            q_stride, p->dim, mb, mq_pad, p->dp, p->qstage.as<float>(),
-                           p->rnq.as<float>() + q0, vec_ok, copy_stride);
+                           p->rnq.as<float>() + q0, vec_ok, copy_stride, 0, (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
         CSLAM_TRY(launch_scan(p, p->qstage.as<float>(), mb, dots + (int64_t)q0 * dots_stride,
                               dots_stride, st));
@@ -2613,7 +2617,7 @@ int best_scan_candidates(cslam_pool* p, const float* q_dev, int64_t q_stride, in
         const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_stage_queries, dim3(16, 1), dim3(256), 0, st, q_dev, q_stride,
                            p->dim, m, 16, p->dp, p->qstage.as<float>(), p->rnq.as<float>(),
-                           vec_ok, (int64_t)0);
+                           vec_ok, (int64_t)0, 0, (int64_t)0);
         CSLAM_HIP_TRY(hipGetLastError());
         qsrc = p->qstage.as<float>();
         qs = p->dp;
@@ -3352,14 +3356,16 @@ int64_t pool_staged_floats(const cslam_pool_t* p, int m) {
     return p && m > 0 ? (int64_t)((m + 15) / 16 * 16) * p->dp : 0;
 }
 int pool_stage_queries_on(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
-                          float* staged, float* staged_rnq, hipStream_t st) {
-    if (!p || !queries_dev || !staged || !staged_rnq || m < 1 || query_stride < p->dim)
+                          float* staged, float* staged_rnq, hipStream_t st, int group_rows, int64_t group_stride) {
+    if (!p || !queries_dev || !staged || !staged_rnq || m < 1 || query_stride < p->dim || group_rows < 0 ||
+        (group_rows > 0 && group_stride < (int64_t)group_rows * query_stride))
         return fail(CSLAM_E_INVALID, "pool_stage_queries_on: bad args");
     CSLAM_HIP_TRY(hipSetDevice(p->device));
     const int mq_pad = (m + 15) / 16 * 16;
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(queries_dev) & 15) == 0 && (query_stride & 3) == 0) ? 1 : 0;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(queries_dev) & 15) == 0 && (query_stride & 3) == 0 &&
+                        (group_stride & 3) == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_stage_queries, dim3(mq_pad, 1), dim3(256), 0, st, queries_dev, query_stride, p->dim, m,
-                       mq_pad, p->dp, staged, staged_rnq, vec_ok, (int64_t)0);
+                       mq_pad, p->dp, staged, staged_rnq, vec_ok, (int64_t)0, group_rows, group_stride);
     CSLAM_HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -241,9 +241,14 @@ __global__ __launch_bounds__(256) void k_records_from_candidates(
 __global__ __launch_bounds__(256) void k_unpack_exchange(const char* __restrict__ pack, int64_t per_rank_bytes,
                                                          int64_t hdr_off, int R, int b_max, int dim,
                                                          float* __restrict__ all_rows,
-                                                         int64_t* __restrict__ all_meta) {
+                                                         int64_t* __restrict__ all_meta, int rows_too) {
     const int s = blockIdx.y;
     const char* src = pack + (int64_t)s * per_rank_bytes;
+    if (blockIdx.x == 0) {
+        const int64_t* meta = reinterpret_cast<const int64_t*>(src + hdr_off);
+        for (int i = threadIdx.x; i < 1 + b_max; i += 256) all_meta[(int64_t)s * (1 + b_max) + i] = meta[i];
+    }
+    if (!rows_too) return;   // the scan's query block is staged straight from `pack` (publish)
     const int64_t n4 = (int64_t)b_max * dim / 4;   // dim is a multiple of 4 here (16-byte copies), else scalar
     const float* rows = reinterpret_cast<const float*>(src);
     float* dst = all_rows + (int64_t)s * b_max * dim;
@@ -254,10 +259,6 @@ __global__ __launch_bounds__(256) void k_unpack_exchange(const char* __restrict_
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)b_max * dim; i += (int64_t)gridDim.x * 256)
             dst[i] = rows[i];
-    }
-    if (blockIdx.x == 0) {
-        const int64_t* meta = reinterpret_cast<const int64_t*>(src + hdr_off);
-        for (int i = threadIdx.x; i < 1 + b_max; i += 256) all_meta[(int64_t)s * (1 + b_max) + i] = meta[i];
     }
 }
 
@@ -279,6 +280,7 @@ struct Slot {
     float* staged = nullptr;          // best2, 17..80 gathered descriptors: the multi-tile scan's query block
     float* staged_rnq = nullptr;      // ... and inverse norms, staged at publish time on the exchange stream
     bool staged_valid = false;        // this step's block was staged at publish time
+    bool rows_valid = true;           // all_rows holds this step's gathered rows (false: staged from `pack`, rows not unpacked)
     cslam_match_record_t* recs_all = nullptr;     // [R][3*R*b_max]  (own part at index me)
     cslam_match_record_t* recs_host = nullptr;    // pinned copy
     hipEvent_t ev_src = nullptr, ev_pub = nullptr, ev_match = nullptr, ev_done = nullptr;
@@ -512,22 +514,28 @@ int cslam_shard_publish(cslam_shard_t* sh, const float* new_rows_dev, int64_t ro
     // ONE collective: rows and (count, keyframe ids) of every rank
     if (R > 1)
         CSLAM_TRY(cslam_comm_allgather(sh->comm_desc, my_pack, s.pack, sh->per_rank_bytes, CSLAM_COMM_OWN_STREAM));
-    {
-        const int64_t n4 = (int64_t)bm * dim / 4;
-        unsigned gx = (unsigned)((n4 + 255) / 256);
-        gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-        hipLaunchKernelGGL(k_unpack_exchange, dim3(gx, R), dim3(256), 0, ps, s.pack, sh->per_rank_bytes, sh->hdr_off, R, bm,
-                           dim, s.all_rows, s.all_meta);
-        CSLAM_HIP_TRY(hipGetLastError());
-    }
     // Stage the gathered block for the multi-tile scan here, on the exchange stream - but only when that
     // scan leaves CUs free: a scan block fills a CU (registers and LDS), so beside a scan on every CU the
     // staging kernel would only queue up in front of the NEXT scan, where it costs more than on the
     // matching stream itself (cfg4, 25 000 rows: 0.216 ms per step with 60 CUs free, 0.267-0.297 without
-    // them against 0.245; profiles/r03_shard_pack_prestage_ab.txt)
-    s.staged_valid = s.staged != nullptr && pool_mq_free_cus(sh->pool, R * bm, s.n0 + b) >= 16;
+    // them against 0.245; profiles/r03_shard_pack_prestage_ab.txt).  A staged block is read STRAIGHT from the
+    // exchange buffer (one part per rank: rows, then the header) and only the headers are unpacked: the
+    // dense copy of the rows is made later, by match(), in the rare case a path without the staged block
+    // runs (ensure_rows) - one 1.3-MB copy and its launch less per step on the exchange stream.
+    s.staged_valid = s.staged != nullptr && (sh->per_rank_bytes & 15) == 0 &&
+                     pool_mq_free_cus(sh->pool, R * bm, s.n0 + b) >= 16;
+    s.rows_valid = !s.staged_valid;
+    {
+        const int64_t n4 = (int64_t)bm * dim / 4;
+        unsigned gx = (unsigned)((n4 + 255) / 256);
+        gx = !s.rows_valid ? 1 : (gx < 1 ? 1 : (gx > 64 ? 64 : gx));
+        hipLaunchKernelGGL(k_unpack_exchange, dim3(gx, R), dim3(256), 0, ps, s.pack, sh->per_rank_bytes, sh->hdr_off, R, bm,
+                           dim, s.all_rows, s.all_meta, s.rows_valid ? 1 : 0);
+        CSLAM_HIP_TRY(hipGetLastError());
+    }
     if (s.staged_valid)
-        CSLAM_TRY(pool_stage_queries_on(sh->pool, s.all_rows, dim, R * bm, s.staged, s.staged_rnq, ps));
+        CSLAM_TRY(pool_stage_queries_on(sh->pool, reinterpret_cast<const float*>(s.pack), dim, R * bm, s.staged,
+                                        s.staged_rnq, ps, bm, sh->per_rank_bytes / 4));
     CSLAM_HIP_TRY(hipEventRecord(s.ev_pub, ps));
     s.b = b;
     s.step = sh->pub_step++;
@@ -552,6 +560,19 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     // this step's searches read rows [0, hi) only, complete since ev_pub: they do not wait for the
     // appends of later steps that the exchange stream has already queued
     PoolInternalScope internal(sh->pool);
+    // the dense copy of the gathered rows, for the paths that read their queries from all_rows (publish left it
+    // out when it staged the block for the multi-tile scan)
+    auto ensure_rows = [&]() -> int {
+        if (s.rows_valid) return CSLAM_OK;
+        const int64_t n4 = (int64_t)bm * dim / 4;
+        unsigned gx = (unsigned)((n4 + 255) / 256);
+        gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+        hipLaunchKernelGGL(k_unpack_exchange, dim3(gx, R), dim3(256), 0, st, s.pack, sh->per_rank_bytes, sh->hdr_off, R,
+                           bm, dim, s.all_rows, s.all_meta, 1);
+        CSLAM_HIP_TRY(hipGetLastError());
+        s.rows_valid = true;
+        return CSLAM_OK;
+    };
     cslam_match_record_t* my_recs = s.recs_all + (int64_t)me * sh->rec_slots;
     const unsigned gm = (unsigned)(((M > s.b ? M : s.b) + 255) / 256);
     if (R == 1 && sh->k_local == 0) {
@@ -573,6 +594,7 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
                                s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, bc.a, bc.c, bc.stride, bc.n,
                                my_recs);
         } else {
+            CSLAM_TRY(ensure_rows());
             CSLAM_TRY(cslam_pool_search_best_split_dev(sh->pool, s.all_rows, dim, M, n0, hi, s.idx_a,
                                                        s.sim_a, s.idx_c, s.sim_c, st));
             hipLaunchKernelGGL((k_make_records<false>), dim3(gm), dim3(256), 0, st, me, R, bm,
@@ -585,6 +607,7 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         // (round 4) the scan leaves the parts' composites and the dots; rank select AND records in one launch
         // behind it.  Where that scan does not run for this shape (tiny pools, K > 32, several passes):
         // the pool's own search, then the records.  CSLAM_SHARD_FUSE_TOPK=0: always the latter (A/B).
+        CSLAM_TRY(ensure_rows());
         static const bool fuse_env = !(getenv("CSLAM_SHARD_FUSE_TOPK") && atoi(getenv("CSLAM_SHARD_FUSE_TOPK")) == 0);
         TopkCandidates tc;
         bool applied = false;
@@ -612,6 +635,7 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
     } else {
         // bulk blocks: best old row of every FOREIGN descriptor (the own block is skipped: two
         // calls around it), best new row through the row-range search
+        CSLAM_TRY(ensure_rows());
         hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_a, (int64_t)M, -1);
         hipLaunchKernelGGL(k_fill_i32, dim3(gm), dim3(256), 0, st, s.idx_c, (int64_t)M, -1);
         const int lo_n = me * bm, hi_first = (me + 1) * bm, hi_n = M - hi_first;

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from cslam_amd import _lib  # noqa: E402
+if os.environ.get("CSLAM_PROBE_LIB"):   # another build of the library (A/B of two builds in one call)
+    _lib.LIB_PATH = os.environ["CSLAM_PROBE_LIB"]
 from cslam_amd.multi_robot import DeviceShard, LoopbackComm  # noqa: E402
 from cslam_amd.nns_matching import NearestNeighborsMatching  # noqa: E402
 
