@@ -3242,7 +3242,8 @@ int cslam_pool_search(cslam_pool_t* p, const float* queries, int n_queries, int 
                     break;
             }
         }
-        if (!seen) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
+        // (every 4096th call synchronises whatever it saw: the runtime gets to retire the stream's commands for good)
+        if (!seen || (seq & 4095u) == 0) CSLAM_HIP_TRY(hipStreamSynchronize(p->stream));
         memcpy(out_idx, idx_pin, obytes * sizeof(int32_t));
         memcpy(out_sim, sim_pin, obytes * sizeof(float));
         p->dev_pending = false;
