@@ -44,7 +44,7 @@ constexpr int kTopkPartsMax = 65535; // part numbers are kept in 16 bits
 // k_scan_dma: the window's n rows split evenly over n_waves (launch_scan_dma)
 struct WaveParts {
     int64_t wq, wrem;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
+    __host__ __device__ void range(int c, int64_t& lo, int& cnt) const {
         lo = c * wq + (c < wrem ? c : wrem);
         cnt = (int)(wq + (c < wrem ? 1 : 0));
     }
@@ -56,7 +56,7 @@ struct WaveParts {
 struct PanelParts {
     int64_t n_main, n;
     int n_blocks, p_max, nw, ns, n_main_parts;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
+    __host__ __device__ void range(int c, int64_t& lo, int& cnt) const {
         if (c >= n_main_parts) {
             lo = n_main + ((int64_t)(c - n_main_parts) << 4);
             const int64_t left = n - lo;
@@ -81,19 +81,19 @@ struct PanelParts {
     }
 };
 
-// (the body: ONE query - its part maxima cq[0..n_parts), its dots dq[0..n), 1/||q|| = rq - by one 256-thread
-// block; results to oi/os[0..k).  Block-uniform control flow; callers that run it for several queries in a row
-// put a barrier between two calls.)
 // k_small_search<true>: part s is strip s of the window (16 rows)
 struct StripParts {
     int64_t n;
-    __device__ void range(int c, int64_t& lo, int& cnt) const {
+    __host__ __device__ void range(int c, int64_t& lo, int& cnt) const {
         lo = (int64_t)c << 4;
         const int64_t left = n - lo;
         cnt = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
     }
 };
 
+// (the body: ONE query - its part maxima cq[0..n_parts), its dots dq[0..n), 1/||q|| = rq - by one 256-thread
+// block; results to oi/os[0..k).  Block-uniform control flow; callers that run it for several queries in a row
+// put a barrier between two calls.)
 template <class Parts>
 __device__ inline void topk_from_parts_body(const uint64_t* cq, int n_parts, const Parts& parts,
                                             const float* dq, const float* __restrict__ rnx,
