@@ -73,9 +73,10 @@ class MAC:
         self._L_odom = None
         self.last_iters = 0
         self.trace_directions = False   # set True: fw_subset also records every direction s_i
-        self.direction_trace = []
-        self.upper_trace = np.zeros(0)
-        self.solver_iters_trace = np.zeros(0, np.int32)
+        self._direction_trace = []
+        self._upper_trace = np.zeros(0)
+        self._solver_iters_trace = np.zeros(0, np.int32)
+        self._trace_pending = None       # (iterations, k) of the last fw_subset whose trace was not read yet
 
     # ---- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -224,7 +225,11 @@ class MAC:
             _lib.ptr(self.lambda_trace)))
         self.fw_iters = its.value
         self.lambda_trace = self.lambda_trace[:its.value]
-        self._read_fw_trace(its.value, int(k))
+        # per-iteration diagnostics (dual bounds, solver iterations, directions) stay on the device until somebody
+        # asks: 20 small reads cost a selection round 1 ms of its 27
+        self._trace_pending = (its.value, int(k))
+        if self.trace_directions:
+            self._read_fw_trace()
         if its.value < max_iters or (its.value > 0 and max_iters > 0 and
                                      upper.value - self.lambda_trace[-1] < duality_gap_tol):
             print("Duality gap tolerance reached, found optimal solution")  # mac.py:224
@@ -234,13 +239,33 @@ class MAC:
             w_round = self._resolve_boundary_tie(w_relaxed, w_round, k)
         return w_round, w_relaxed, upper.value
 
-    def _read_fw_trace(self, iters, k):
-        """Per-iteration diagnostics of the last fw_subset call: dual bounds u_i (mac.py:219),
-        solver iteration counts and — with `trace_directions` — the directions s_i (mac.py:215) as
-        ascending index arrays."""
-        self.upper_trace = np.empty(iters)
-        self.solver_iters_trace = np.empty(iters, np.int32)
-        self.direction_trace = []
+    @property
+    def upper_trace(self):
+        """Dual bounds u_i of the last fw_subset call (mac.py:219)."""
+        self._read_fw_trace()
+        return self._upper_trace
+
+    @property
+    def solver_iters_trace(self):
+        """Eigen-solver iterations per Frank-Wolfe iteration of the last fw_subset call."""
+        self._read_fw_trace()
+        return self._solver_iters_trace
+
+    @property
+    def direction_trace(self):
+        """With `trace_directions`: the directions s_i (mac.py:215) of the last fw_subset call, ascending indices."""
+        self._read_fw_trace()
+        return self._direction_trace
+
+    def _read_fw_trace(self):
+        """Fetch the per-iteration diagnostics of the last fw_subset call from the device (once)."""
+        if self._trace_pending is None or not self._handle:
+            return
+        iters, k = self._trace_pending
+        self._trace_pending = None
+        self._upper_trace = np.empty(iters)
+        self._solver_iters_trace = np.empty(iters, np.int32)
+        self._direction_trace = []
         u = ctypes.c_double()
         f = ctypes.c_double()
         si = ctypes.c_int32()
@@ -250,10 +275,10 @@ class MAC:
             _lib.check(self._lib.cslam_mac_fw_trace_read(
                 self._handle, it, _lib.ptr(idx) if idx is not None else None, ctypes.byref(n_idx),
                 ctypes.byref(f), ctypes.byref(u), ctypes.byref(si)))
-            self.upper_trace[it] = u.value
-            self.solver_iters_trace[it] = si.value
+            self._upper_trace[it] = u.value
+            self._solver_iters_trace[it] = si.value
             if idx is not None:
-                self.direction_trace.append(idx[:n_idx.value].copy())
+                self._direction_trace.append(idx[:n_idx.value].copy())
 
     def stats(self):
         """(solver iterations so far, device ms of the last fiedler / fw_subset call)."""
