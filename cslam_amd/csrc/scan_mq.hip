@@ -40,6 +40,7 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
+#include "mq_plan.hpp"
 #include "probe_hooks.hpp"
 
 using namespace cslam;
@@ -713,10 +714,7 @@ int mq_waves_available(int waves) {   // for the main launch; the K-split launch
     return waves == 4;
 #endif
 }
-int mq_panel_strips(int tiles, int waves) {
-    if (waves == 8) return tiles >= 5 ? 3 : (tiles == 4 ? 4 : (tiles == 3 ? 5 : 8));
-    return tiles >= 4 ? 6 : 8;   // acc + tot = 8 NS T AccVGPRs of 256: eight strips up to three tiles, six beyond
-}
+int mq_panel_strips(int tiles, int waves) { return mq_panel_strips_of(tiles, waves); }   // (mq_plan.hpp)
 
 int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool nt, hipStream_t st) {
     if (mode == kMqModePart && a.part_ks < 1) return fail(CSLAM_E_INVALID, "scan_mq: K parts");
