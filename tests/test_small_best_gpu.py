@@ -306,3 +306,40 @@ def test_device_calls_on_several_streams_stay_ordered(gpu):
             np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
             assert sim.cpu().numpy().tobytes() == o_sim.tobytes()
     p.close()
+
+
+def test_two_threads_two_pools(gpu):
+    """Two host threads, each with a pool of its own (the node matches against one pool per robot), call the
+    host-pointer API at the same time - every call polls its own pool's completion word and uses its own pool's
+    scratch: every answer is the oracle's."""
+    import threading
+    rs = np.random.RandomState(9)
+    pools, data = [], []
+    for n, d in ((1000, 128), (3000, 128), (9000, 256)):
+        X = rs.rand(n, d).astype(np.float32) - 0.3
+        Q = rs.rand(40, d).astype(np.float32) - 0.2
+        o1 = oracle_knn.search(X, Q, 1)
+        o10 = oracle_knn.search(X, Q, 10)
+        pools.append(_pool(X))
+        data.append((Q, o1, o10))
+    errors = []
+
+    def work(i):
+        try:
+            p = pools[i]
+            Q, (i1, s1, _), (i10, s10, _) = data[i]
+            for rep in range(150):
+                j = rep % len(Q)
+                item, sim = p.search_best(Q[j])
+                assert item == int(i1[j, 0]) and np.float32(sim).tobytes() == s1[j, :1].astype(np.float32).tobytes(), (i, rep)
+                items, sims = p.search(Q[j], 10)
+                assert items == [int(r) for r in i10[j]] and np.asarray(sims).tobytes() == s10[j].astype(np.float32).tobytes(), (i, rep)
+        except Exception as e:     # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(pools))]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    assert not errors, errors
+    for p in pools:
+        p.close()
