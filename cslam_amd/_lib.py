@@ -101,6 +101,7 @@ SIGNATURES = {
     "cslam_mac_fw_subset": (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_double, _vp, _vp,
                                        _f64p, _i32p, _vp]),
     "cslam_knobs_reload": (_c.c_int, []),
+    "cslam_pool_flush_dev": (_c.c_int, [_vp]),
     "cslam_mac_fw_trace_enable": (_c.c_int, [_vp, _c.c_int]),
     "cslam_mac_fw_trace_read": (_c.c_int, [_vp, _c.c_int32, _vp, _i64p, _f64p, _f64p, _i32p]),
     "cslam_mac_stats": (_c.c_int, [_vp, _i64p, _f64p]),

@@ -1,5 +1,6 @@
 #include "common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace cslam {
@@ -25,6 +26,21 @@ int device_cu_count(int device_id, int* cus) {
     *cus = prop.multiProcessorCount;
     return CSLAM_OK;
 }
+
+namespace {
+std::atomic<int> g_knob_generation{1};
+}
+int knob(Knob& k) {
+    static const bool live = getenv("CSLAM_KNOBS_LIVE") != nullptr;
+    const int g = g_knob_generation.load(std::memory_order_relaxed);
+    if (live || k.generation.load(std::memory_order_acquire) != g) {
+        const char* s = getenv(k.name);
+        k.value.store(s ? atoi(s) : k.def, std::memory_order_relaxed);
+        k.generation.store(g, std::memory_order_release);
+    }
+    return k.value.load(std::memory_order_relaxed);
+}
+void knobs_invalidate() { g_knob_generation.fetch_add(1, std::memory_order_acq_rel); }
 
 }  // namespace cslam
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -84,6 +85,21 @@ struct PinBuf {
 };
 
 int device_cu_count(int device_id, int* cus);
+
+// Measurement / A-B knobs (environment variables, KNOBS.md): read ONCE per process, then cached.  Two ways to
+// have them read again, both for tests and tools only: cslam_knobs_reload() (every knob re-reads its variable
+// at its next use: a test changes one setting, reloads, and reloads again when it restores the environment)
+// and CSLAM_KNOBS_LIVE (every use re-reads: tools that alternate settings launch by launch, inside one
+// process - boxes and processes differ by more than the effects in question).  Fields are atomics: shards
+// run as threads of one process (tests/test_shard_gpu.py).  Use: `static Knob k{"CSLAM_X", 1}; knob(k)`.
+struct Knob {
+    const char* name;
+    int def;
+    std::atomic<int> value{0};
+    std::atomic<int> generation{0};
+};
+int knob(Knob& k);
+void knobs_invalidate();   // what cslam_knobs_reload() does
 
 // knn.hip → shard.hip (internal).  pool_append_on: cslam_pool_add_dev without the cross-stream
 // ordering of the public entry points (the shard orders its streams with its own events);

@@ -1814,28 +1814,8 @@ bool dma_scan_applies(const cslam_pool* p) {
 // measurement knobs: read once — or at every launch when CSLAM_KNOBS_LIVE is set, so that a tool can
 // alternate settings inside one process (tools/reserve_ab.py; boxes and processes differ by
 // more than the effects in question)
-// Measurement / A-B knobs (environment variables): read ONCE per process, then cached.  Two ways to have
-// them read again, both for tests and tools only: cslam_knobs_reload() (every knob re-reads its variable
-// at its next use: a test changes one setting, reloads, and reloads again when it restores the
-// environment) and CSLAM_KNOBS_LIVE (every use re-reads: tools that alternate settings launch by
-// launch).  Fields are atomics: shards run as threads of one process (tests/test_shard_gpu.py).
-std::atomic<int> g_knob_generation{1};
-struct Knob {
-    const char* name;
-    int def;
-    std::atomic<int> value{0};
-    std::atomic<int> generation{0};
-};
-int knob(Knob& k) {
-    static const bool live = getenv("CSLAM_KNOBS_LIVE") != nullptr;
-    const int g = g_knob_generation.load(std::memory_order_relaxed);
-    if (live || k.generation.load(std::memory_order_acquire) != g) {
-        const char* s = getenv(k.name);
-        k.value.store(s ? atoi(s) : k.def, std::memory_order_relaxed);
-        k.generation.store(g, std::memory_order_release);
-    }
-    return k.value.load(std::memory_order_relaxed);
-}
+// (measurement / A-B knobs: `Knob` + `knob()` of common.hpp - read once per process, cslam_knobs_reload() and
+// CSLAM_KNOBS_LIVE have them read again)
 bool dev_event_eager() {   // CSLAM_DEV_EVENT=1: record the device-API event behind every *_dev call (mark_dev)
     static Knob k_eager{"CSLAM_DEV_EVENT", 0};
     return knob(k_eager) != 0;
@@ -2163,6 +2143,33 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
     a.cand_c = (cand_c != nullptr && split >= 0) ? cand_c : nullptr;
     if (g.tail_strips > 0)
         CSLAM_TRY(p->part.reserve((size_t)g.tail_strips * g.nchunks * g.tiles * 64 * sizeof(f32x4)));
+    // The launch geometry against what the buffers hold, on the host, before anything is launched (the kernels
+    // clamp their addresses into the window MqArgs describes - tools/probes/mq_probe_audit.hpp checks that
+    // half on the device; a window or a plan that does not fit the allocations must never reach them).
+    {
+        const int64_t strips = (p->vn + 15) / 16, strips_main = (g.n_main + 15) / 16;
+        const bool window_ok = p->v0 >= 0 && p->vn > 0 && p->v0 + p->vn <= p->n && p->n <= p->cap;
+        const bool plan_ok = g.tiles >= 2 && g.tiles <= mq_max_tiles() && m <= mq_pad && g.n_main >= 0 &&
+                             g.n_main <= p->vn && (g.n_main == p->vn || g.n_main % 16 == 0) &&
+                             (g.n_main == p->vn ? g.tail_strips == 0 : g.tail_strips == strips - g.n_main / 16) &&
+                             (g.n_main == 0 ||
+                              (g.n_blocks >= 1 && (int64_t)g.p_max * g.waves * mq_panel_strips(g.tiles, g.waves) >=
+                                                      (strips_main + g.n_blocks - 1) / g.n_blocks)) &&
+                             (g.tail_strips == 0 || (g.tail_groups >= 1 && g.tail_ks >= 1 && g.tail_ks <= g.nchunks &&
+                                                     (int64_t)g.tail_groups * g.tail_ks <= 65535)) &&
+                             g.nchunks == (p->dp + 511) / 512 && p->dp % g.kw == 0 && p->dp % g.part_kw == 0;
+        const bool stage_ok = staged != nullptr || p->qstage.bytes >= (size_t)mq_pad * p->dp * sizeof(float);
+        const bool cand_ok = !best || (cand != nullptr && cand_stride >= g.n_cand &&
+                                       g.n_cand == (int64_t)g.n_blocks * g.p_max * g.waves + g.tail_strips);
+        const bool dots_ok = dots == nullptr || dots_stride >= p->vn;
+        if (!(window_ok && plan_ok && stage_ok && cand_ok && dots_ok && (best || dots != nullptr)))
+            return fail(CSLAM_E_INVALID,
+                        "mq_pass: launch does not fit its buffers (window %d plan %d stage %d cand %d dots %d; rows %lld+%lld of "
+                        "%lld/%lld, main %lld, tail %lld as %d x %d, blocks %d x %d rounds)",
+                        (int)window_ok, (int)plan_ok, (int)stage_ok, (int)cand_ok, (int)dots_ok, (long long)p->v0,
+                        (long long)p->vn, (long long)p->n, (long long)p->cap, (long long)g.n_main,
+                        (long long)g.tail_strips, g.tail_groups, g.tail_ks, g.n_blocks, g.p_max);
+    }
     bool prof = prof_take(p);
     if (prof) CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n], st));
     if (g.n_main > 0)
@@ -3139,8 +3146,17 @@ int cslam_pool_profile_begin_sampled(cslam_pool_t* p, int max_samples, int every
 
 
 int cslam_knobs_reload(void) {
-    g_knob_generation.fetch_add(1, std::memory_order_acq_rel);
+    knobs_invalidate();
     return CSLAM_OK;
+}
+
+// The ordering event of the device-pointer API is recorded lazily (mark_dev): by the first later call that
+// needs it, on the stream the last *_dev call went to - i.e. behind whatever the caller has queued there
+// since.  A caller that is about to queue unrelated work on that stream, or to destroy it, records it here.
+int cslam_pool_flush_dev(cslam_pool_t* p) {
+    if (!p) return fail(CSLAM_E_INVALID, "pool_flush_dev: bad args");
+    CSLAM_HIP_TRY(hipSetDevice(p->device));
+    return dev_event_now(p);
 }
 
 const char* cslam_pool_scan_kernel(const cslam_pool_t* p) { return p ? p->last_scan_kernel : ""; }

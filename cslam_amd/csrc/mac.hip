@@ -2320,8 +2320,10 @@ struct cslam_mac {
     int trace_cap = 0;
     bool fw_trace_on = false;        // cslam_mac_fw_trace_enable: also record every direction s_i
     int32_t* strace_d = nullptr;     // [strace_cap][strace_k] indices of s_i, ascending
-    int strace_cap = 0;
-    int64_t strace_k = 0;
+    size_t strace_elems = 0;         // int32 entries allocated (grows only)
+    int strace_cap = 0;              // iterations (rows) of the LAST fw_subset call that recorded directions
+    int64_t strace_k = 0;            // ... and its k: row stride, bound of k_fw_record_s and length trace_read copies
+    bool strace_valid = false;       // the last fw_subset call recorded its directions
     int fw_trace_iters = 0;          // iterations the last fw_subset call recorded
     double* dual_part = nullptr;     // per-block partials of the duality-gap dot product
     long long* prof = nullptr;
@@ -3111,16 +3113,24 @@ int cslam_mac_fw_subset(cslam_mac_t* mac, const double* w_init, int64_t k, int m
         mac->trace_cap = max_iters;
     }
     mac->fw_trace_iters = 0;
-    if (mac->fw_trace_on && (max_iters > mac->strace_cap || k > mac->strace_k)) {
-        if (mac->strace_d) (void)hipFree(mac->strace_d);
-        mac->strace_d = nullptr;
-        mac->strace_cap = 0;
-        mac->strace_k = 0;
-        CSLAM_TRY(dev_alloc(&mac->strace_d, (size_t)max_iters * (size_t)std::max<int64_t>(k, 1)));
+    // the direction trace is laid out for THIS call: rows of exactly k entries (a buffer kept from a call
+    // with a larger k has room to spare, never a larger stride: trace_read copies strace_k entries into a
+    // host buffer of the caller's k)
+    const bool record_s = mac->fw_trace_on && k > 0 && k <= m && max_iters > 0;
+    mac->strace_valid = false;
+    if (record_s) {
+        const size_t want = (size_t)max_iters * (size_t)k;
+        if (want > mac->strace_elems) {
+            if (mac->strace_d) (void)hipFree(mac->strace_d);
+            mac->strace_d = nullptr;
+            mac->strace_elems = 0;
+            CSLAM_TRY(dev_alloc(&mac->strace_d, want));
+            mac->strace_elems = want;
+        }
         mac->strace_cap = max_iters;
         mac->strace_k = k;
+        mac->strace_valid = true;
     }
-    const bool record_s = mac->fw_trace_on && k > 0 && k <= m;
     Scalars h;
     std::memset(&h, 0, sizeof(h));
     h.fw_u = INFINITY;
@@ -3251,7 +3261,7 @@ int cslam_mac_fw_trace_read(cslam_mac_t* mac, int32_t it, int32_t* s_idx, int64_
     for (int q = 0; q < 3; ++q)
         CSLAM_HIP_TRY(hipMemcpyAsync(&h[q], mac->trace_d + (size_t)q * mac->trace_cap + it, sizeof(double),
                                      hipMemcpyDeviceToHost, mac->stream));
-    const bool have_s = mac->fw_trace_on && mac->strace_d && it < mac->strace_cap;
+    const bool have_s = mac->strace_valid && mac->strace_d && it < mac->strace_cap;
     if (s_idx && have_s)
         CSLAM_HIP_TRY(hipMemcpyAsync(s_idx, mac->strace_d + (size_t)it * mac->strace_k,
                                      sizeof(int32_t) * mac->strace_k, hipMemcpyDeviceToHost, mac->stream));

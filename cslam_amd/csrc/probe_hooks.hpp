@@ -1,4 +1,4 @@
-// Hook points of the scan kernels for TIMING PROBES.  The product build defines every hook empty (and
+// Hook points of the scan kernels for TIMING PROBES and the ADDRESS AUDIT.  The product build defines every hook empty (and
 // the two functional macros as the real operation): no probe code lives in the shipped translation
 // units.  A probe build (tools/build_mq_probes.sh) compiles the same sources with
 // -DCSLAM_PROBE_HOOKS_FILE='"../../tools/probes/<probe>.hpp"', which defines the hooks it needs before
@@ -36,6 +36,23 @@
 #endif
 #ifndef CSLAM_MQ_REFILL                 // false: the ring is never refilled
 #define CSLAM_MQ_REFILL true
+#endif
+
+// Address audit (tools/probes/mq_probe_audit.hpp): every global address the kernel is about to use is compared
+// with what MqArgs says the operand holds; a violation is logged and the access redirected (loads: AUDIT_SRC
+// may replace the pointer variable) or left out (stores: AUDIT_DST / AUDIT_IDX guard the block behind them).
+// kinds: 0 pool rows, 1 staged queries, 2 query norms, 3 row norms, 4 chunk partials, 5 composites, 6 dots
+#ifndef CSLAM_MQ_AUDIT_SRC
+#define CSLAM_MQ_AUDIT_SRC(kind, ptr, bytes)
+#endif
+#ifndef CSLAM_MQ_AUDIT_DST
+#define CSLAM_MQ_AUDIT_DST(kind, ptr, bytes)
+#endif
+#ifndef CSLAM_MQ_AUDIT_IDX
+#define CSLAM_MQ_AUDIT_IDX(kind, idx, bound)
+#endif
+#ifndef CSLAM_MQ_AUDIT_COMBINE
+#define CSLAM_MQ_AUDIT_COMBINE
 #endif
 
 // ---- k_scan_dma (knn.hip) ------------------------------------------------------------------------

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     uint32_t i_climit = (uint32_t)i_last * xs_b + (uint32_t)seg * 16u;
     auto issue_piece = [&](int pp, int sl) {
         const uint32_t off = full_off[pp] < i_climit ? full_off[pp] : i_climit;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(i_base + off),
+        const char* src = i_base + off;
+        CSLAM_MQ_AUDIT_SRC(0, src, 16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(ring + sl * kStage + pp * kPiece),
                                          16, 0, AUX);
     };
@@ -235,8 +237,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
             uint32_t lo = b_lane_off;
             asm volatile("" : "+v"(lo));
             const char* ub = b_cur + (uint32_t)x * b_stride;
+            const char* src = ub + lo;
+            CSLAM_MQ_AUDIT_SRC(1, src, 16)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(ub + lo),
+                (const __attribute__((address_space(1))) void*)src,
                 (__attribute__((address_space(3))) void*)(bbuf + (bb * T * NP + pi) * kPiece), 16, 0, 0);
             ++issued;
         }
@@ -255,11 +259,15 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
     // ceiling; loaded in the epilogue they would drain the ring (hipcc waits vmcnt(0) for an ordinary load).
     if (MODE == MODE_BEST) {
         const int qi = lane < 16 * T ? lane : 16 * T - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.rnq + qi),
+        const char* src = reinterpret_cast<const char*>(A.rnq + qi);
+        CSLAM_MQ_AUDIT_SRC(2, src, 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(rvbuf + 512), 4, 0, 0);
         if (16 * T > 64) {
             const int qj = 64 + lane < 16 * T ? 64 + lane : 16 * T - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.rnq + qj),
+            const char* src2 = reinterpret_cast<const char*>(A.rnq + qj);
+            CSLAM_MQ_AUDIT_SRC(2, src2, 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src2,
                                              (__attribute__((address_space(3))) void*)(rvbuf + 512 + 256), 4, 0, 0);
         }
         issued += 16 * T > 64 ? 2 : 1;   // older than everything the waits of the stage loop count
@@ -331,9 +339,13 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                 const uint32_t o0 = (uint32_t)(lane < last ? lane : last) * 4u;
                 const uint32_t o1 = (uint32_t)(64 + lane < last ? 64 + lane : last) * 4u;
                 const char* rb = reinterpret_cast<const char*>(A.rnx + lo_c);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + o0),
+                const char* src0 = rb + o0;
+                const char* src1 = rb + o1;
+                CSLAM_MQ_AUDIT_SRC(3, src0, 4)
+                CSLAM_MQ_AUDIT_SRC(3, src1, 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src0,
                                                  (__attribute__((address_space(3))) void*)rvbuf, 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + o1),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src1,
                                                  (__attribute__((address_space(3))) void*)(rvbuf + 256), 4, 0, 0);
                 issued += 2;
                 mark_rv = issued;
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                             f32x4* out = A.part + ((strip * nchunks_all + c) * T) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                out[t * 64] = acc[s][t];
+                                CSLAM_MQ_AUDIT_DST(4, out + t * 64, 16) { out[t * 64] = acc[s][t]; }
                                 acc[s][t] = zero4;
                                 asm volatile("" : "+a"(acc[s][t]));
                             }
@@ -540,8 +552,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                 }
                 // one composite per query and panel; a panel without rows leaves the empty composite
                 if (eg == 0 && 16 * t + er < A.m_valid) {
-                    A.cand[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best;
-                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best_c;
+                    CSLAM_MQ_AUDIT_IDX(5, pidx, (int64_t)A.n_blocks * A.p_max * NW) {
+                        A.cand[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best;
+                        if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + er) * A.cand_stride + pidx] = best_c;
+                    }
                 }
                 // search with k > 1 (k_topk_from_parts): the raw dots beside the composites (wave-uniform)
                 if (A.dots != nullptr && 16 * t + er < A.m_valid) {
@@ -551,7 +565,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                         if (s < ns) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (16 * s + 4 * eg + e < rows) out[16 * s + e] = tot[s][t][e];
+                                if (16 * s + 4 * eg + e < rows) {
+                                    CSLAM_MQ_AUDIT_IDX(6, lo + 16 * s + 4 * eg + e, A.n) { out[16 * s + e] = tot[s][t][e]; }
+                                }
                         }
                     }
                 }
@@ -568,7 +584,9 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                             float* out = A.dots + (int64_t)(16 * t + r) * A.dots_stride + r0;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (r0 + e < hi) out[e] = tot[s][t][e];
+                                if (r0 + e < hi) {
+                                    CSLAM_MQ_AUDIT_IDX(6, r0 + e, A.n) { out[e] = tot[s][t][e]; }
+                                }
                         }
                     }
                 }
@@ -582,8 +600,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (16 * t + r < A.m_valid) {
-                    A.cand[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
-                    if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
+                    CSLAM_MQ_AUDIT_IDX(5, pidx, (int64_t)A.n_blocks * A.p_max * NW) {
+                        A.cand[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
+                        if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + pidx] = 0;
+                    }
                 }
         }
     }
@@ -608,6 +628,7 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
     const int64_t hi = lo + 16 < A.n ? lo + 16 : A.n;
     const int rows = (int)(hi - lo);
     const f32x4* src = A.part + ((strip * nchunks) * tiles + t) * 64 + lane;
+    CSLAM_MQ_AUDIT_COMBINE
     f32x4 part[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c)
@@ -722,7 +743,8 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
     // no running totals, so NS strips x T tiles of accumulators fit 256 registers per wave
     if (mode == kMqModePart && waves == 8 && kw == 64 && tiles >= 2 && tiles <= 5 && a.dp % 64 == 0 && a.n > 0 &&
         a.n_blocks >= 1) {
-        static const int ns_env = getenv("CSLAM_MQ_PART_NS") ? atoi(getenv("CSLAM_MQ_PART_NS")) : 0;   // A/B: strips per panel
+        static Knob k_ns{"CSLAM_MQ_PART_NS", 0};   // A/B: strips per panel
+        const int ns_env = knob(k_ns);
         if (tiles == 5 && ns_env == 3) return launch_one<5, 64, 3, 3, 0, MODE_PART, 8>(a, st);
         if (tiles == 5 && ns_env == 2) return launch_one<5, 64, 3, 2, 0, MODE_PART, 8>(a, st);
         if (tiles == 5 && ns_env == 4) return launch_one<5, 64, 3, 4, 0, MODE_PART, 8>(a, st);

@@ -400,7 +400,8 @@ int cslam_shard_create(cslam_pool_t* pool, cslam_comm_t* comm_desc, cslam_comm_t
         A(dalloc(&s.all_rows, M * sh->dim));
         A(dalloc(&s.all_meta, (size_t)nb_robots * (1 + max_block)));
         A(dalloc(&s.recs_all, (size_t)nb_robots * sh->rec_slots));
-        static const bool prestage = !(getenv("CSLAM_SHARD_PRESTAGE") && atoi(getenv("CSLAM_SHARD_PRESTAGE")) == 0);
+        static Knob k_prestage{"CSLAM_SHARD_PRESTAGE", 1};
+        const bool prestage = knob(k_prestage) != 0;
         if (sh->best2 && M > 16 && prestage) {
             // the gathered block is staged for the multi-tile scan as soon as it has landed (publish), on
             // the exchange stream: the staging launch leaves the matching stream's critical path
@@ -608,7 +609,8 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         // behind it.  Where that scan does not run for this shape (tiny pools, K > 32, several passes):
         // the pool's own search, then the records.  CSLAM_SHARD_FUSE_TOPK=0: always the latter (A/B).
         CSLAM_TRY(ensure_rows());
-        static const bool fuse_env = !(getenv("CSLAM_SHARD_FUSE_TOPK") && atoi(getenv("CSLAM_SHARD_FUSE_TOPK")) == 0);
+        static Knob k_fuse{"CSLAM_SHARD_FUSE_TOPK", 1};
+        const bool fuse_env = knob(k_fuse) != 0;
         TopkCandidates tc;
         bool applied = false;
         if (fuse_env)

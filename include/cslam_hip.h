@@ -123,6 +123,15 @@ int cslam_pool_profile_begin(cslam_pool_t* pool, int max_launches);
 /* same, bracketing only every `every`-th launch (an event pair costs ~8 us of stream time). */
 int cslam_pool_profile_begin_sampled(cslam_pool_t* pool, int max_samples, int every);
 int cslam_pool_profile_end(cslam_pool_t* pool, double* avg_scan_ms, int* n_launches);
+/* Ordering of the *_dev entry points against calls on OTHER streams (the host-pointer API runs on the pool's
+ * own stream): an event behind the last *_dev call, which the next call on another stream waits for.  The
+ * event is recorded LAZILY - by that next call, on the stream the *_dev work went to, i.e. behind everything
+ * the caller has queued on that stream since.  Consequences for the caller: (1) the stream handed to a *_dev
+ * call must stay alive until the pool's next call on any other stream (or cslam_pool_flush_dev /
+ * cslam_pool_destroy); (2) unrelated work queued on that stream behind the *_dev call delays that next
+ * call.  cslam_pool_flush_dev records the event NOW: call it behind the last *_dev call of a batch before
+ * queueing unrelated work on the stream or destroying it.  No-op when nothing is pending. */
+int cslam_pool_flush_dev(cslam_pool_t* pool);
 /* Measurement knobs (CSLAM_* environment variables) are read once per process; after this
  * call every knob re-reads its variable at its next use.  For tests and A/B tools, not for the node. */
 int cslam_knobs_reload(void);

@@ -43,7 +43,8 @@ def knobs(monkeypatch):
     lib = _lib.load()
 
     class Knobs(object):
-        touched = set()
+        def __init__(self):
+            self.touched = set()     # per fixture instance, i.e. per test
 
         def set(self, name, value):
             monkeypatch.setenv(name, str(value))

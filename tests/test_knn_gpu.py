@@ -301,6 +301,49 @@ def test_device_append_is_ordered_before_host_api(gpu):
     m.close()
 
 
+def test_flush_dev_pins_the_ordering_event_behind_the_device_call(gpu):
+    """cslam_pool_flush_dev records the (lazily kept) ordering event NOW: the caller's stream may then be
+    destroyed, and unrelated work queued on it afterwards does not stand between the device-pointer append
+    and the next host-pointer search (include/cslam_hip.h, INTEGRATION.md "Streams of the device-pointer calls")."""
+    import time
+    torch = pytest.importorskip("torch")
+    from cslam_amd import _lib
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    rs = np.random.RandomState(5)
+    base = rs.rand(600, 256).astype(np.float32)
+    blk = rs.rand(40, 256).astype(np.float32)
+    m = NearestNeighborsMatching(dim=256)
+    m.add_items(base, list(range(600)))
+    assert gpu.cslam_pool_flush_dev(m.handle) == 0          # nothing pending: no-op
+    side = torch.cuda.Stream()
+    big = torch.rand((8192, 8192), device="cuda")
+    blk_d = torch.from_numpy(blk).cuda()
+    torch.cuda.synchronize()
+    m.search_batch(blk[:1], 1)                              # warm the host path
+    with torch.cuda.stream(side):
+        m.add_items_tensor(blk_d, list(range(600, 640)))
+        _lib.check(gpu.cslam_pool_flush_dev(m.handle))
+        for _ in range(40):                                 # unrelated work BEHIND the flushed event
+            big = big @ big
+            big /= big.norm()
+    t0 = time.perf_counter()
+    rows, sims = m.search_batch(blk[11:12], 1)              # waits for the append only
+    t_host = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    side.synchronize()
+    t_rest = time.perf_counter() - t1
+    assert rows[0, 0] == 611 and abs(sims[0, 0] - 1.0) < 1e-6
+    assert t_rest > 5 * t_host, (t_host, t_rest)            # the matmuls were still running when the search returned
+    # the stream goes away behind a flush; the pool's next calls never touch it again
+    with torch.cuda.stream(side):
+        m.add_items_tensor(blk_d[:3].contiguous(), list(range(640, 643)))
+        _lib.check(gpu.cslam_pool_flush_dev(m.handle))
+    del side
+    rows, _ = m.search_batch(blk[2:3], 1)
+    assert rows[0, 0] in (602, 642)
+    m.close()
+
+
 def test_ring_and_dma_scan_variants_are_bit_identical(gpu, monkeypatch):
     """CSLAM_SCAN_KERNEL=ring (round 1's register-ring kernel) and the default LDS-DMA scan (here on
     209 one-strip panels with partial strips) must give the same bits: both implement the one

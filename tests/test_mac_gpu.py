@@ -80,6 +80,60 @@ def test_fw_subset_matches_reference(gpu, case):
     mac.close()
 
 
+def test_direction_trace_with_a_shrinking_budget_on_one_handle(gpu):
+    """The direction trace is laid out for the k of the LAST fw_subset call: a call with a smaller k on
+    the same handle must not keep the earlier call's row stride (cslam_mac_fw_trace_read copies k entries
+    into a caller buffer of k: ADVICE r04), nor hand back stale entries of the earlier call."""
+    import ctypes
+    from cslam_amd import _lib
+    mac, g = _mac(CASES[1])
+    m = len(mac.weights)
+    k_big = int(g("nb")[3])
+    k_small = max(2, k_big // 3)
+    mac.trace_directions = True
+
+    def run(k, iters):
+        with redirect_stdout(io.StringIO()):
+            mac.fw_subset(g("w_init"), k, max_iters=iters)
+        return [d.copy() for d in mac.direction_trace]
+
+    first = run(k_big, 6)
+    small = run(k_small, 6)
+    again = run(k_big, 4)
+    # a fresh handle that only ever saw the small budget is the yardstick
+    fresh, _ = _mac(CASES[1])
+    fresh.trace_directions = True
+    with redirect_stdout(io.StringIO()):
+        fresh.fw_subset(g("w_init"), k_small, max_iters=6)
+    want = [d.copy() for d in fresh.direction_trace]
+    assert len(small) == len(want) == 6
+    for got, ref in zip(small, want):
+        assert got.shape == (k_small,) and np.all(np.diff(got) > 0) and got.max() < m
+        np.testing.assert_array_equal(got, ref)
+    for a, b in zip(again, first):       # and growing back reproduces the first call's directions
+        np.testing.assert_array_equal(a, b)
+    # the bare C call: n_idx is the k of the last call, and nothing is written behind s_idx[k)
+    with redirect_stdout(io.StringIO()):
+        mac.fw_subset(g("w_init"), k_small, max_iters=3)
+    buf = np.full(k_small + 64, -7, np.int32)
+    n_idx = ctypes.c_int64()
+    f, u, si = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+    _lib.check(_lib.load().cslam_mac_fw_trace_read(mac._handle, 1, _lib.ptr(buf), ctypes.byref(n_idx),
+                                                   ctypes.byref(f), ctypes.byref(u), ctypes.byref(si)))
+    assert n_idx.value == k_small
+    assert np.all(buf[k_small:] == -7)
+    np.testing.assert_array_equal(buf[:k_small], want[1])
+    # tracing switched off: the next call reports no directions (not the previous call's)
+    mac.trace_directions = False
+    with redirect_stdout(io.StringIO()):
+        mac.fw_subset(g("w_init"), k_small, max_iters=3)
+    _lib.check(_lib.load().cslam_mac_fw_trace_read(mac._handle, 1, _lib.ptr(buf), ctypes.byref(n_idx),
+                                                   ctypes.byref(f), ctypes.byref(u), ctypes.byref(si)))
+    assert n_idx.value == 0
+    fresh.close()
+    mac.close()
+
+
 def test_round_solution_and_topk(gpu):
     from cslam_amd.mac.mac import MAC
     from cslam_amd.mac.utils import Edge

@@ -99,3 +99,51 @@ def test_split_window_through_the_k_split_pass(gpu):
         np.testing.assert_array_equal(ic.cpu().numpy(), oc[:, 0] + split)
         assert sc.cpu().numpy().tobytes() == osc[:, 0].astype(np.float32).tobytes()
     p.close()
+
+
+def test_pools_of_60000_then_12000_rows_in_one_process_under_alternating_plans(gpu, knobs):
+    """The sequence behind the unexplained memory fault of profiles/r04_mq_plan_ab_2.txt: one process, a
+    60 000-row x 4096-d pool scanned with 80 queries under the seven plan settings of that day, alternating, then -
+    its buffers freed - a 12 000-row pool under the same alternation (the record stops where the second pool starts).
+    Every setting must give the oracle's bits on both pools; mq_pass checks every launch against the pool's
+    allocations on the host, tools/mq_audit.py runs the same sequence with every device address checked
+    (profiles/README.md, r05_mq_audit.txt)."""
+    import torch
+    from cslam_amd import _lib
+    from cslam_amd.nns_matching import NearestNeighborsMatching
+    settings = [
+        {"CSLAM_MQ_TAIL_SHAPE": "2", "CSLAM_MQ_ALLPART": "0"}, {}, {"CSLAM_MQ_TAIL_SHAPE": "1", "CSLAM_MQ_ALLPART": "0"},
+        {"CSLAM_MQ_TAIL": "0"}, {"CSLAM_MQ_ALLPART_GROUPS": "32", "CSLAM_MQ_ALLPART_KS": "8"},
+        {"CSLAM_MQ_ALLPART_GROUPS": "64", "CSLAM_MQ_ALLPART_KS": "4"}, {"CSLAM_MQ_ALLPART_GROUPS": "128", "CSLAM_MQ_ALLPART_KS": "2"},
+    ]
+    d, m = 4096, 80
+    gen = torch.Generator(device="cuda").manual_seed(618)
+    for n in (60000, 12000):
+        Xd = torch.rand((n, d), device="cuda", generator=gen)
+        Qd = torch.rand((m, d), device="cuda", generator=gen)
+        p = NearestNeighborsMatching(dim=d, capacity_hint=n)
+        p.add_items_device(Xd.data_ptr(), n, d, items=None, stream=None)
+        idx = torch.empty((m, 1), dtype=torch.int32, device="cuda"); sim = torch.empty((m, 1), device="cuda")
+        X = Xd.cpu().numpy(); Q = Qd.cpu().numpy()
+        # the oracle on 16 of the 80 queries (strict-chain C: the full block would take the CPU half a minute)
+        sel = np.arange(0, m, 5)
+        o_idx, o_sim, _ = oracle_knn.search(X, Q[sel], 1)
+        ref = None
+        seen = set()
+        for rep in range(2):
+            for env in settings:
+                knobs.only(env)
+                for _ in range(4):
+                    _lib.check(gpu.cslam_pool_search_dev(p.handle, ctypes.c_void_p(Qd.data_ptr()), d, m, 1,
+                                                         ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sim.data_ptr()), None))
+                torch.cuda.synchronize()
+                seen.add(gpu.cslam_pool_scan_kernel(p.handle).decode())
+                out = (idx.cpu().numpy().copy(), sim.cpu().numpy().copy())
+                if ref is None:
+                    ref = out
+                    np.testing.assert_array_equal(out[0][sel, 0], o_idx[:, 0])
+                    assert out[1][sel, 0].tobytes() == o_sim[:, 0].astype(np.float32).tobytes()
+                assert out[0].tobytes() == ref[0].tobytes() and out[1].tobytes() == ref[1].tobytes(), (n, env)
+        assert len(seen) >= 2, seen
+        p.close()
+        del Xd, Qd, idx, sim
