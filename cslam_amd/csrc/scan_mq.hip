@@ -40,6 +40,7 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
+#include "mq_combine.hpp"
 #include "mq_plan.hpp"
 #include "probe_hooks.hpp"
 
@@ -54,6 +55,21 @@ constexpr int MODE_DOTS = 0, MODE_BEST = 1, MODE_PART = 2;
 template <int... I, class F>
 __device__ inline void static_for(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
+}
+
+// A chunk partial leaves for the scratch array k_mq_combine reads right behind this launch.
+// CSLAM_MQ_PART_STORE (compile time, A/B): 0 plain store, 1 non-temporal, 2 write-through (sc0 sc1).
+#ifndef CSLAM_MQ_PART_STORE
+#define CSLAM_MQ_PART_STORE 0
+#endif
+__device__ inline void mq_store_partial(f32x4* dst, const f32x4& v) {
+#if CSLAM_MQ_PART_STORE == 1
+    __builtin_nontemporal_store(v, dst);
+#elif CSLAM_MQ_PART_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#else
+    *dst = v;
+#endif
 }
 
 template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
                             f32x4* out = A.part + ((strip * nchunks_all + c) * T) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                CSLAM_MQ_AUDIT_DST(4, out + t * 64, 16) { out[t * 64] = acc[s][t]; }
+                                CSLAM_MQ_AUDIT_DST(4, out + t * 64, 16) { mq_store_partial(out + t * 64, acc[s][t]); }
                                 acc[s][t] = zero4;
                                 asm volatile("" : "+a"(acc[s][t]));
                             }
@@ -626,55 +642,22 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
     const int64_t lo = strip << 4;
     if (lo >= A.n) return;
     const int64_t hi = lo + 16 < A.n ? lo + 16 : A.n;
-    const int rows = (int)(hi - lo);
     const f32x4* src = A.part + ((strip * nchunks) * tiles + t) * 64 + lane;
     CSLAM_MQ_AUDIT_COMBINE
-    f32x4 part[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-        part[c] = c < nchunks ? src[(int64_t)c * tiles * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 tot{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (c < nchunks) tot = tot + part[c];
-    for (int c = 16; c < nchunks; ++c) tot = tot + src[(int64_t)c * tiles * 64];   // dp > 8192
+    const f32x4 tot = mq_fold_partials(src, tiles, nchunks);   // (mq_combine.hpp: shared with the fused final level)
     if (BEST) {
-        float rn[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t row = lo + 4 * g + e;
-            rn[e] = A.rnx[row < A.n ? row : A.n - 1];
-        }
-        const bool two = A.split < hi;
-        const uint32_t rbase = A.row0 + (uint32_t)lo;
-        const int srel = A.split > lo ? (int)((A.split < hi ? A.split : hi) - lo) : 0;
-        const float rq = A.rnq[16 * t + r];
-        uint64_t best = 0, best_c = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int rel = 4 * g + e;
-            const float sim = (tot[e] * rn[e]) * rq;
-            uint64_t c = make_comp(sim, rbase + (uint32_t)rel);
-            c = rel < rows ? c : 0;
-            if (two) {
-                const uint64_t ca = rel < srel ? c : 0, cc = rel < srel ? 0 : c;
-                best = ca > best ? ca : best;
-                best_c = cc > best_c ? cc : best_c;
-            } else {
-                best = c > best ? c : best;
-            }
-        }
-        uint64_t o = __shfl_xor(best, 16, 64);
-        best = o > best ? o : best;
-        o = __shfl_xor(best, 32, 64);
-        best = o > best ? o : best;
-        o = __shfl_xor(best_c, 16, 64);
-        best_c = o > best_c ? o : best_c;
-        o = __shfl_xor(best_c, 32, 64);
-        best_c = o > best_c ? o : best_c;
+        MqBest2 b = mq_strip_composites(A, tot, lo, hi, g, A.rnq[16 * t + r]);
+        uint64_t o = __shfl_xor(b.a, 16, 64);
+        b.a = o > b.a ? o : b.a;
+        o = __shfl_xor(b.a, 32, 64);
+        b.a = o > b.a ? o : b.a;
+        o = __shfl_xor(b.c, 16, 64);
+        b.c = o > b.c ? o : b.c;
+        o = __shfl_xor(b.c, 32, 64);
+        b.c = o > b.c ? o : b.c;
         if (g == 0 && 16 * t + r < A.m_valid) {
-            A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best;
-            if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = best_c;
+            A.cand[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = b.a;
+            if (A.cand_c != nullptr) A.cand_c[(int64_t)(16 * t + r) * A.cand_stride + cand_off + strip] = b.c;
         }
     }
     // raw dots: dots mode, and beside the composites for search with k > 1 (k_topk_from_parts)

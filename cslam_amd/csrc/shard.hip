@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "composite.hpp"
+#include "mq_combine.hpp"
 #include "topk_parts.hpp"
 
 using namespace cslam;
@@ -187,23 +188,24 @@ __global__ __launch_bounds__(256) void k_topk_records(
 // Split best-match mode, final level and records in ONE launch behind the scan: block i reduces
 // the waves' composites of gathered descriptor i (best old row, best row of the new block) and
 // its first thread writes the two inter-robot record slots exactly like k_make_records<false>.
-__global__ __launch_bounds__(256) void k_records_from_candidates(
-    int me, int nb_robots, int b_max, const int64_t* __restrict__ all_meta, int64_t n0,
-    int32_t* __restrict__ kf_of_row, int b_own, double thr, const uint64_t* __restrict__ cand_a,
-    const uint64_t* __restrict__ cand_c, int64_t cand_stride, int64_t n_cand,
-    cslam_match_record_t* __restrict__ recs) {
-    __shared__ uint64_t scratch[4];
-    const int i = blockIdx.x;
-    const uint64_t ba = block_max_u64(cand_a + (int64_t)i * cand_stride, n_cand, scratch);
-    const uint64_t bc = block_max_u64(cand_c + (int64_t)i * cand_stride, n_cand, scratch);
-    if (threadIdx.x != 0) return;
-    const int64_t* own_meta = all_meta + (int64_t)me * (1 + b_max);
-    if (i < b_own) kf_of_row[n0 + i] = (int32_t)own_meta[1 + i];
+struct RecordArgs {
+    int me, nb_robots, b_max;
+    const int64_t* all_meta;
+    int64_t n0;
+    int32_t* kf_of_row;
+    int b_own;
+    double thr;
+    cslam_match_record_t* recs;
+};
+// the record slots of gathered descriptor i from its two winners (best old row, best row of the new block)
+__device__ inline void records_of_descriptor(const RecordArgs& R, int i, uint64_t ba, uint64_t bc) {
+    const int64_t* own_meta = R.all_meta + (int64_t)R.me * (1 + R.b_max);
+    if (i < R.b_own) R.kf_of_row[R.n0 + i] = (int32_t)own_meta[1 + i];
     auto kf_at = [&](int32_t row) {
-        return row >= n0 ? (int32_t)own_meta[1 + (row - n0)] : kf_of_row[row];
+        return row >= R.n0 ? (int32_t)own_meta[1 + (row - R.n0)] : R.kf_of_row[row];
     };
-    const int s = i / b_max, j = i % b_max;
-    const int64_t* meta = all_meta + (int64_t)s * (1 + b_max);
+    const int s = i / R.b_max, j = i % R.b_max;
+    const int64_t* meta = R.all_meta + (int64_t)s * (1 + R.b_max);
     cslam_match_record_t none;
     none.robot0_id = -1;
     none.robot0_keyframe_id = 0;
@@ -211,28 +213,48 @@ __global__ __launch_bounds__(256) void k_records_from_candidates(
     none.robot1_keyframe_id = 0;
     none.weight = 0.f;
     cslam_match_record_t r0 = none, r1 = none;
-    if (j < (int)meta[0] && s != me) {
+    if (j < (int)meta[0] && s != R.me) {
         const int32_t kf_s = (int32_t)meta[1 + j];
         const int32_t ia = comp_row(ba), ic = comp_row(bc);
         const float sa = comp_sim(ba), sc = comp_sim(bc);
-        if (ia >= 0 && (double)sa >= thr) {  // lcsm.py:69-75
-            r0.robot0_id = me;
+        if (ia >= 0 && (double)sa >= R.thr) {  // lcsm.py:69-75
+            r0.robot0_id = R.me;
             r0.robot0_keyframe_id = kf_at(ia);
             r0.robot1_id = s;
             r0.robot1_keyframe_id = kf_s;
             r0.weight = sa;
         }
-        if (ic >= 0 && (double)sc >= thr && !(ia >= 0 && sa >= sc)) {  // lcsm.py:47-55, on the peer's behalf
+        if (ic >= 0 && (double)sc >= R.thr && !(ia >= 0 && sa >= sc)) {  // lcsm.py:47-55, on the peer's behalf
             r1.robot0_id = s;
             r1.robot0_keyframe_id = kf_s;
-            r1.robot1_id = me;
+            r1.robot1_id = R.me;
             r1.robot1_keyframe_id = kf_at(ic);
             r1.weight = sc;
         }
     }
-    recs[3 * (int64_t)i + 0] = r0;
-    recs[3 * (int64_t)i + 1] = r1;
-    recs[3 * (int64_t)i + 2] = none;
+    R.recs[3 * (int64_t)i + 0] = r0;
+    R.recs[3 * (int64_t)i + 1] = r1;
+    R.recs[3 * (int64_t)i + 2] = none;
+}
+__global__ __launch_bounds__(256) void k_records_from_candidates(
+    const RecordArgs R, const uint64_t* __restrict__ cand_a, const uint64_t* __restrict__ cand_c,
+    int64_t cand_stride, int64_t n_cand) {
+    __shared__ uint64_t scratch[4];
+    const int i = blockIdx.x;
+    const uint64_t ba = block_max_u64(cand_a + (int64_t)i * cand_stride, n_cand, scratch);
+    const uint64_t bc = block_max_u64(cand_c + (int64_t)i * cand_stride, n_cand, scratch);
+    if (threadIdx.x != 0) return;
+    records_of_descriptor(R, i, ba, bc);
+}
+// (round 5) ... and as the tail of the multi-tile scan's fused fold + final level (mq_combine.hpp): where the
+// whole window of the pool went through the K-split launch, thread i of k_mq_combine_final's last block writes
+// descriptor i's record slots - no launch of its own behind the combine
+struct RecordsFinal {
+    RecordArgs R;
+    __device__ void operator()(int i, uint64_t ba, uint64_t bc) const { records_of_descriptor(R, i, ba, bc); }
+};
+int launch_records_final(const MqArgs& a, int tiles, int nchunks, const MqFinalScratch& fs, void* ctx, hipStream_t st) {
+    return launch_mq_combine_final(a, tiles, nchunks, fs, *static_cast<const RecordsFinal*>(ctx), nullptr, 0u, st);
 }
 
 // The gathered exchange buffer holds, per rank, [b_max][dim] fp32 rows followed by the (count,
@@ -586,14 +608,17 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         // ONE scan launch: best row before n0 and best row of the new block per gathered
         // descriptor; its candidates are reduced by the record kernel itself
         BestCandidates bc;
-        bool applied = false;
+        bool applied = false, records_done = false;
+        RecordsFinal rfin{{me, R, bm, s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, my_recs}};
+        const MqFinalHook hook{launch_records_final, &rfin};
         CSLAM_TRY(pool_best_split_candidates(sh->pool, s.all_rows, dim, M, n0, hi, st, &bc, &applied,
                                              s.staged_valid ? s.staged : nullptr,
-                                             s.staged_valid ? s.staged_rnq : nullptr));
-        if (applied) {
-            hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, me, R, bm,
-                               s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, bc.a, bc.c, bc.stride, bc.n,
-                               my_recs);
+                                             s.staged_valid ? s.staged_rnq : nullptr, &hook, &records_done));
+        if (applied && records_done) {
+            // (the scan's fused final level wrote the records)
+        } else if (applied) {
+            hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, rfin.R, bc.a, bc.c, bc.stride,
+                               bc.n);
         } else {
             CSLAM_TRY(ensure_rows());
             CSLAM_TRY(cslam_pool_search_best_split_dev(sh->pool, s.all_rows, dim, M, n0, hi, s.idx_a,

@@ -62,7 +62,7 @@ def test_every_form_of_the_pass_gives_the_same_bits(gpu, knobs, n, d, m, k):
     kk = int(o_cnt[0])
     seen = set()
     for env in ({}, {"CSLAM_MQ_ALLPART": "0"}, {"CSLAM_MQ_ALLPART": "2"}, {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_PART_WAVES": "4"},
-                {"CSLAM_MQ_ALLPART": "0", "CSLAM_MQ_TAIL_SHAPE": "2"}):
+                {"CSLAM_MQ_ALLPART": "0", "CSLAM_MQ_TAIL_SHAPE": "2"}, {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_FINAL": "0"}):
         knobs.only(env)
         p = _pool(X)
         rows, sims = p.search_batch(Q, k)
@@ -147,3 +147,46 @@ def test_pools_of_60000_then_12000_rows_in_one_process_under_alternating_plans(g
         assert len(seen) >= 2, seen
         p.close()
         del Xd, Qd, idx, sim
+
+
+def test_fused_final_level_of_the_k_split_pass(gpu, knobs):
+    """Where the whole window goes through the K-split launch, search_best ends in ONE launch behind it: fold, epilogue
+    and final level (k_mq_combine_final, csrc/mq_combine.hpp) - atomic maxima of the strips' composites + a ticket -
+    instead of k_mq_combine + k_best_pair.  Same bits as the two-launch form and as the oracle; the scratch cleans
+    itself: query counts going down and up on one pool, the split search in between, ties -> lowest row."""
+    import torch
+    from cslam_amd import _lib
+    n, d = 25000, 512
+    X, Q = _data(n, d, 80, 4242)
+    X[n - 1] = X[5]; X[16 * 700 + 3] = X[5]; Q[7] = X[5]          # three equal rows in different strips
+    p = _pool(X)
+    qd = torch.from_numpy(Q).cuda()
+    o_idx, o_sim, _ = oracle_knn.search(X, Q, 1)
+    for m in (80, 33, 48, 80, 17):
+        rows, sims = p.search_batch(Q[:m], 1)
+        name = gpu.cslam_pool_scan_kernel(p.handle).decode()
+        assert (name.endswith("k_mq_combine_final")) == (m > 32), (m, name)   # two tiles never take the all-K-split form
+        np.testing.assert_array_equal(rows, o_idx[:m, :1])
+        assert sims.tobytes() == o_sim[:m, :1].astype(np.float32).tobytes()
+        assert m <= 7 or rows[7, 0] == 5
+        if m == 48:   # the split search through the same launch, then back
+            split = 16 * 700 + 5
+            ia = torch.empty(m, dtype=torch.int32, device="cuda"); sa = torch.empty(m, device="cuda")
+            ic = torch.empty(m, dtype=torch.int32, device="cuda"); sc = torch.empty(m, device="cuda")
+            _lib.check(gpu.cslam_pool_search_best_split_dev(p.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split, n,
+                                                            ctypes.c_void_p(ia.data_ptr()), ctypes.c_void_p(sa.data_ptr()),
+                                                            ctypes.c_void_p(ic.data_ptr()), ctypes.c_void_p(sc.data_ptr()), None))
+            torch.cuda.synchronize()
+            assert gpu.cslam_pool_scan_kernel(p.handle).decode().endswith("k_mq_combine_final")
+            oa, osa, _ = oracle_knn.search(X[:split], Q[:m], 1)
+            oc, osc, _ = oracle_knn.search(X[split:], Q[:m], 1)
+            np.testing.assert_array_equal(ia.cpu().numpy(), oa[:, 0])
+            assert sa.cpu().numpy().tobytes() == osa[:, 0].astype(np.float32).tobytes()
+            np.testing.assert_array_equal(ic.cpu().numpy(), oc[:, 0] + split)
+            assert sc.cpu().numpy().tobytes() == osc[:, 0].astype(np.float32).tobytes()
+    knobs.set("CSLAM_MQ_FINAL", "0")
+    rows2, sims2 = p.search_batch(Q, 1)
+    assert gpu.cslam_pool_scan_kernel(p.handle).decode().endswith("k_mq_combine<best>")
+    np.testing.assert_array_equal(rows2, o_idx[:, :1])
+    assert sims2.tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
+    p.close()

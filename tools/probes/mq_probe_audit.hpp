@@ -9,7 +9,8 @@
 // up as a log entry instead of a memory fault of the GPU.  Results of this build are the product's (the audit
 // changes no address that is in range); it is slower.  The host side of the chain - MqArgs against the pool's
 // allocations - is checked by knn.hip::mq_pass in every build.
-// Read the log with cslam_probe_mq_audit_read (tools/mq_audit.py).
+// Read the log with cslam_probe_mq_audit_read (tools/mq_audit.py).  -DCSLAM_MQ_AUDIT_SELFTEST: negative control
+// (the last row of the window counts as out of range: the log must fill, results must change).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -34,6 +35,9 @@ __device__ inline void mq_audit_range(const Args& A, int kind, int tiles16, cons
         case 0:
             *lo = reinterpret_cast<const char*>(A.X);
             *hi = reinterpret_cast<const char*>(A.X + (A.n - 1) * A.xs + A.dp);
+#if defined(CSLAM_MQ_AUDIT_SELFTEST)   // negative control: the window's last row is declared out of range
+            *hi = reinterpret_cast<const char*>(A.X + (A.n - 2) * A.xs + A.dp);
+#endif
             break;
         case 1:
             *lo = reinterpret_cast<const char*>(A.Q);
