@@ -124,15 +124,10 @@ struct BestCandidates {
 };
 // staged = the block pool_stage_queries_on() left for these m queries (17..80: the multi-tile scan then
 // skips its own staging launch), or nullptr
-// fin != nullptr: where the pass can end in the fused fold + final level (mq_combine.hpp) it launches `fin` instead of
-// its own combine and reports *fin_done = true - the caller then launches NO final kernel of its own (out is not
-// filled in that case)
-struct MqFinalHook;
 int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
                                int64_t split_row, int64_t row_hi, hipStream_t st,
                                BestCandidates* out, bool* applied, const float* staged = nullptr,
-                               const float* staged_rnq = nullptr, const MqFinalHook* fin = nullptr,
-                               bool* fin_done = nullptr);
+                               const float* staged_rnq = nullptr);
 // What a best-match scan with dots leaves for the rank select of topk_parts.hpp (search with 2 <= k <= 32): the
 // best composite of every part of the window [row_lo, row_hi) - waves of k_scan_dma (kind 0) or panels / K-split
 // strips of k_scan_mq (kind 1) - and the raw dots of every row.  The caller launches the select itself (the

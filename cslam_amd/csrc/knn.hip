@@ -27,7 +27,6 @@
 #include "composite.hpp"
 #include "dma_scan.hpp"
 #include "scan_mq.hpp"
-#include "mq_combine.hpp"
 #include "mq_plan.hpp"
 #include "topk_parts.hpp"
 #include "probe_hooks.hpp"
@@ -1647,7 +1646,6 @@ struct cslam_pool {
     hipStream_t stream = nullptr;
     DevBuf qstage, rnq, sims, cand_a, cand_b, cand_c, comp, part;
     DevBuf small_scratch;              // k_small_best: 16 composites + the ticket, zero between calls
-    DevBuf mq_final_scratch;           // k_mq_combine_final: 2 x 96 composites + the ticket, zero between launches
     uint32_t small_seq = 0;            // call number the host polls for (host-pointer API)
     uint32_t* done_word = nullptr;     // armed by cslam_pool_search's small path: the call's final launch signals it
     bool done_taken = false;
@@ -2060,7 +2058,7 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
     static Knob k_tail{"CSLAM_MQ_TAIL", 1}, k_kw{"CSLAM_MQ_KW", 0}, k_waves{"CSLAM_MQ_WAVES", 4};
     static Knob k_rounds{"CSLAM_MQ_TAIL_ROUNDS", 6}, k_shape{"CSLAM_MQ_TAIL_SHAPE", 0}, k_cost{"CSLAM_MQ_TAIL_MAXCOST", 80};
     static Knob k_allpart{"CSLAM_MQ_ALLPART", 1}, k_allpart_g{"CSLAM_MQ_ALLPART_GROUPS", 0}, k_allpart_k{"CSLAM_MQ_ALLPART_KS", 0};
-    static Knob k_part_waves{"CSLAM_MQ_PART_WAVES", 8}, k_pack{"CSLAM_MQ_PACK_BLOCKS", 1};
+    static Knob k_part_waves{"CSLAM_MQ_PART_WAVES", 8}, k_pack{"CSLAM_MQ_PACK_BLOCKS", 1}, k_blocks2{"CSLAM_MQ_PART_BLOCKS2", 1};
     MqPlanKnobs kn;
     kn.tail = knob(k_tail);
     kn.kw = knob(k_kw);
@@ -2072,6 +2070,7 @@ MqPlan mq_plan(const cslam_pool* p, int m, int64_t rows = -1, int shard_caller =
     kn.allpart_groups = knob(k_allpart_g);
     kn.allpart_ks = knob(k_allpart_k);
     kn.part_waves = knob(k_part_waves);
+    kn.part_blocks2 = knob(k_blocks2);
     kn.pack_blocks = knob(k_pack);
     MqPlanIn in;
     in.vn = rows >= 0 ? rows : p->vn;
@@ -2107,6 +2106,14 @@ const char* mq_name(const MqPlan& g, bool best) {
               "k_scan_mq<T=4,NW=4,part> + k_mq_combine", "k_scan_mq<T=5,NW=4,part> + k_mq_combine"},
              {"k_scan_mq<T=2,NW=4,part> + k_mq_combine<best>", "k_scan_mq<T=3,NW=4,part> + k_mq_combine<best>",
               "k_scan_mq<T=4,NW=4,part> + k_mq_combine<best>", "k_scan_mq<T=5,NW=4,part> + k_mq_combine<best>"}}};
+        if (g.part_per_cu == 2) {
+            static const char* const two[2][4] = {
+                {"k_scan_mq<T=2,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine", "k_scan_mq<T=3,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine",
+                 "k_scan_mq<T=4,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine", "k_scan_mq<T=5,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine"},
+                {"k_scan_mq<T=2,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine<best>", "k_scan_mq<T=3,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine<best>",
+                 "k_scan_mq<T=4,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine<best>", "k_scan_mq<T=5,KW=64,NST=2,NW=4,2 per CU,part> + k_mq_combine<best>"}};
+            return two[best ? 1 : 0][g.tiles - 2];
+        }
         return part[g.part_waves == 8 ? 0 : 1][best ? 1 : 0][g.tiles - 2];
     }
     return names[g.waves == 8 ? 2 : (g.kw == 128 ? 0 : 1)][best ? 1 : 0][g.tiles - 2];
@@ -2116,9 +2123,7 @@ const char* mq_name(const MqPlan& g, bool best) {
 // (staged != nullptr: the caller staged the queries itself - pool_stage_queries_on - with their norms in rnq)
 int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* rnq, float* dots,
             int64_t dots_stride, bool best, uint64_t* cand, int64_t cand_stride, int64_t split,
-            uint64_t* cand_c, const MqPlan& g, hipStream_t st, const float* staged = nullptr,
-            const MqFinalHook* fin = nullptr, bool* fin_done = nullptr) {
-    if (fin_done) *fin_done = false;
+            uint64_t* cand_c, const MqPlan& g, hipStream_t st, const float* staged = nullptr) {
     const int mq_pad = 16 * g.tiles;
     if (staged == nullptr) {
         const int vec_ok = ((reinterpret_cast<uintptr_t>(q_dev) & 15) == 0 && (q_stride & 3) == 0) ? 1 : 0;
@@ -2191,47 +2196,17 @@ int mq_pass(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, float* r
         b.p_max = 1;
         b.part = p->part.as<f32x4>();
         b.part_ks = g.tail_ks;
+        b.part_per_cu = g.part_per_cu;
         static Knob k_part_nt{"CSLAM_MQ_PART_NT", 1};   // A/B: non-temporal pool reads in the all-K-split launch
         CSLAM_TRY(launch_scan_mq(b, g.tiles, g.part_kw, g.part_waves, kMqModePart,
                                  g.n_main == 0 && g.nt && knob(k_part_nt) != 0, st));
-        // (round 5) best match, the whole window through the K-split launch, no dots: the fold, the epilogue AND
-        // the caller's final level - rows + similarities, or the sharded step's records - in ONE launch
-        // (mq_combine.hpp) instead of k_mq_combine + a launch of the caller's own.  CSLAM_MQ_FINAL=0: never (A/B).
-        static Knob k_final{"CSLAM_MQ_FINAL", 1};
-        if (fin != nullptr && fin->launch != nullptr && best && dots == nullptr && g.n_main == 0 && knob(k_final) != 0) {
-            // (the ticket - and in the atomic variants the running maxima - are zero between launches: the last
-            // block cleans up; a buffer that had to grow starts from zero again)
-            const int64_t tstrips = (b.n + 15) / 16;
-            const size_t want = mq_final_scratch_bytes(tstrips);
-            if (want > p->mq_final_scratch.bytes) {
-                CSLAM_TRY(p->mq_final_scratch.reserve(want));
-                CSLAM_HIP_TRY(hipMemsetAsync(p->mq_final_scratch.p, 0, p->mq_final_scratch.bytes, st));
-            }
-            const int64_t groups = (tstrips + kMqFinalStrips - 1) / kMqFinalStrips;
-            const int64_t per = CSLAM_MQ_FINAL_VARIANT == 2 ? kMqFinalQ * groups : (int64_t)kMqFinalSlots * kMqFinalQ;
-            uint32_t* tick = p->mq_final_scratch.as<uint32_t>();          // [0, 256): the ticket
-            uint64_t* base = reinterpret_cast<uint64_t*>(p->mq_final_scratch.as<char>() + 256);
-            const MqFinalScratch fs{base, base + per, tick, groups};
-            CSLAM_TRY(fin->launch(b, g.tiles, g.nchunks, fs, fin->ctx, st));
-            if (fin_done) *fin_done = true;
-        } else {
-            CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * g.waves, st));
-        }
+        CSLAM_TRY(launch_mq_combine(b, g.tiles, g.nchunks, best, (int64_t)g.n_blocks * g.p_max * g.waves, st));
     }
     if (prof) {
         CSLAM_HIP_TRY(hipEventRecord(p->ev[2 * p->prof_n + 1], st));
         p->prof_n++;
     }
     p->last_scan_kernel = mq_name(g, best);
-    if (fin_done && *fin_done) {   // (static strings: bench.py's roofline line quotes them)
-        static const char* const fused[4] = {
-            "k_scan_mq<T=2,KW=64,NST=3,NW=8,part> + k_mq_combine_final", "k_scan_mq<T=3,KW=64,NST=3,NW=8,part> + k_mq_combine_final",
-            "k_scan_mq<T=4,KW=64,NST=3,NW=8,part> + k_mq_combine_final", "k_scan_mq<T=5,KW=64,NST=3,NW=8,part> + k_mq_combine_final"};
-        static const char* const fused4[4] = {
-            "k_scan_mq<T=2,NW=4,part> + k_mq_combine_final", "k_scan_mq<T=3,NW=4,part> + k_mq_combine_final",
-            "k_scan_mq<T=4,NW=4,part> + k_mq_combine_final", "k_scan_mq<T=5,NW=4,part> + k_mq_combine_final"};
-        p->last_scan_kernel = (g.part_waves == 8 ? fused : fused4)[g.tiles - 2];
-    }
     return CSLAM_OK;
 }
 
@@ -2558,30 +2533,6 @@ bool mq_best_applies(const cslam_pool* p, int m) {
     // select launches (cost model in compute_dots)
     return mq_scan_applies(p, m) && m <= 4 * 16 * mq_max_tiles();
 }
-// the final level of search_best as the tail of k_mq_combine_final: thread q of the launch's last block
-struct BestPairFinal {
-    int32_t* idx_a;
-    float* sim_a;
-    int32_t* idx_c;
-    float* sim_c;
-    __device__ void operator()(int q, uint64_t a, uint64_t c) const {
-        idx_a[q] = comp_row(a);
-        sim_a[q] = comp_sim(a);
-        if (idx_c != nullptr) {
-            idx_c[q] = comp_row(c);
-            sim_c[q] = comp_sim(c);
-        }
-    }
-};
-struct BestPairFinalCtx {
-    BestPairFinal fin;
-    uint32_t* done;
-    uint32_t seq;
-};
-int launch_best_pair_final(const MqArgs& a, int tiles, int nchunks, const MqFinalScratch& fs, void* ctx, hipStream_t st) {
-    const BestPairFinalCtx* c = static_cast<const BestPairFinalCtx*>(ctx);
-    return launch_mq_combine_final(a, tiles, nchunks, fs, c->fin, c->done, c->seq, st);
-}
 int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int64_t split,
                  int32_t* idx_a, float* sim_a, int32_t* idx_c, float* sim_c, hipStream_t st,
                  bool final_call = false) {
@@ -2599,22 +2550,10 @@ int best_scan_mq(cslam_pool* p, const float* q_dev, int64_t q_stride, int m, int
         const int64_t cstride = (g.n_cand + 63) / 64 * 64;
         CSLAM_TRY(p->cand_a.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
         if (split >= 0) CSLAM_TRY(p->cand_c.reserve((size_t)16 * g.tiles * cstride * sizeof(uint64_t)));
-        // (the completion word of the host-pointer API is taken by whichever launch ends the call: the fused
-        // final level knows its last block and needs no ticket of its own)
-        const bool last_pass = final_call && q0 + mb >= m;
-        const bool fusable = g.n_main == 0 && g.tail_strips > 0;
-        DoneArgs dn;
-        if (fusable) dn = take_done(p, last_pass);
-        BestPairFinalCtx fctx{{idx_a + q0, sim_a + q0, (split >= 0 && idx_c) ? idx_c + q0 : nullptr,
-                               (split >= 0 && sim_c) ? sim_c + q0 : nullptr}, dn.word, dn.seq};
-        const MqFinalHook hook{launch_best_pair_final, &fctx};
-        bool fin_done = false;
         CSLAM_TRY(mq_pass(p, q_dev + (int64_t)q0 * q_stride, q_stride, mb, p->rnq.as<float>() + q0, nullptr, 0,
                           true, p->cand_a.as<uint64_t>(), cstride, split,
-                          split >= 0 ? p->cand_c.as<uint64_t>() : nullptr, g, st, nullptr,
-                          fusable && (split < 0 || (idx_c && sim_c)) ? &hook : nullptr, &fin_done));
-        if (fin_done) continue;
-        if (!fusable) dn = take_done(p, last_pass);
+                          split >= 0 ? p->cand_c.as<uint64_t>() : nullptr, g, st));
+        const DoneArgs dn = take_done(p, final_call && q0 + mb >= m);
         hipLaunchKernelGGL(k_best_pair, dim3(mb, split >= 0 ? 2 : 1), dim3(256), 0, st,
                            p->cand_a.as<uint64_t>(), p->cand_c.as<uint64_t>(), cstride, g.n_cand,
                            idx_a + q0, sim_a + q0, idx_c ? idx_c + q0 : nullptr,
@@ -2860,7 +2799,6 @@ int cslam_pool_destroy(cslam_pool_t* p) {
     p->cand_c.release();
     p->comp.release();
     p->part.release();
-    p->mq_final_scratch.release();
     p->small_scratch.release();
     p->h_q.release();
     p->h_idx.release();
@@ -3312,9 +3250,8 @@ int pool_stage_queries_on(cslam_pool_t* p, const float* queries_dev, int64_t que
 int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_t query_stride, int m,
                                int64_t split_row, int64_t row_hi, hipStream_t st,
                                BestCandidates* out, bool* applied, const float* staged,
-                               const float* staged_rnq, const MqFinalHook* fin, bool* fin_done) {
+                               const float* staged_rnq) {
     *applied = false;
-    if (fin_done) *fin_done = false;
     if (!p || m < 1 || m > 16 * mq_max_tiles() || split_row <= 0 || split_row >= row_hi || row_hi > p->n ||
         !queries_dev || query_stride < p->dim)
         return CSLAM_OK;
@@ -3334,7 +3271,7 @@ int pool_best_split_candidates(cslam_pool_t* p, const float* queries_dev, int64_
         CSLAM_TRY(mq_pass(p, queries_dev, query_stride, m,
                           pre ? const_cast<float*>(staged_rnq) : p->rnq.as<float>(), nullptr, 0, true,
                           p->cand_a.as<uint64_t>(), cstride, split_row, p->cand_c.as<uint64_t>(), g, st,
-                          pre ? staged : nullptr, fin, fin_done));
+                          pre ? staged : nullptr));
         out->a = p->cand_a.as<uint64_t>();
         out->c = p->cand_c.as<uint64_t>();
         out->stride = cstride;

@@ -27,6 +27,7 @@ struct MqPlanIn {
 struct MqPlanKnobs {
     int tail = 1, kw = 0, waves = 4, tail_rounds = 6, tail_shape = 0, tail_maxcost = 80;
     int allpart = 1, allpart_groups = 0, allpart_ks = 0, part_waves = 8, pack_blocks = 1;
+    int part_blocks2 = 1;   // the all-K-split launch as TWO four-wave blocks per CU (round 5; CSLAM_MQ_PART_BLOCKS2=0: one eight-wave block)
 };
 
 // A pass is either ONE launch (every wave whole strips of its block's even share) or, when the
@@ -37,6 +38,7 @@ struct MqPlanKnobs {
 struct MqPlan {
     int tiles, kw, waves, n_blocks, p_max;
     int part_kw, part_waves;   // slice width and waves per block of the K-split launch
+    int part_per_cu;           // blocks of the K-split launch a CU holds at once (1; 2 = the two-block form)
     int64_t n_main;      // rows of the main launch (all of them when there is no tail)
     int tail_groups, tail_ks, nchunks;   // K-split tail: strip groups x K parts
     int64_t tail_strips;
@@ -55,6 +57,7 @@ inline MqPlan mq_plan_compute(const MqPlanIn& in, const MqPlanKnobs& kn) {
     if (g.waves == 8) g.kw = 64;                // eight private rings fit the LDS with 4-KiB stages only
     g.part_kw = g.kw;
     g.part_waves = g.waves;
+    g.part_per_cu = 1;
     g.nchunks = (in.dp + 511) / 512;
     const int ns = mq_panel_strips_of(g.tiles, g.waves);
     const int64_t strips = (vn + 15) / 16;
@@ -147,20 +150,29 @@ inline MqPlan mq_plan_compute(const MqPlanIn& in, const MqPlanKnobs& kn) {
         // rings of 4-KiB stages), and the partner wave's MFMAs fill what one wave per SIMD leaves idle at
         // every stage boundary, LDS wait and barrier (in-kernel clock probe: 40 clocks per MFMA with one
         // wave per SIMD, 36 inside the k-blocks, against 32 of the pipe; profiles/r04_mq_clock_probe_1.txt).
-        const int pw = kn.part_waves == 8 && in.dp % 64 == 0 ? 8 : g.waves;
+        // Round 5: the same two waves per SIMD as TWO independent four-wave blocks per CU - 64-float slices, rings
+        // of two stages, 78 KiB of LDS each - so that one block's barrier at a slice step is covered by the other
+        // block's MFMAs (the eight waves of one block all stand at it together); the B slices are fetched twice
+        // per CU.  Pass time, 80 queries x 4096-d, alternating in one process (profiles/r05_blocks2_ab.txt):
+        // 8 000 rows 60.0 -> 57.4 us, 12 000: 80.0 -> 77.9, 25 000: 155.4 -> 151.7, 40 000: 226.9 -> 223.3
+        // (48 / 64 queries: -2 ... -4 % on 8 000 - 25 000 rows, even on 40 000).  CSLAM_MQ_PART_BLOCKS2=0: one
+        // eight-wave block per CU (round 4).
+        const bool two = kn.part_blocks2 != 0 && kn.part_waves == 8 && in.dp % 64 == 0 && g.tiles >= 2;
+        const int pw = two ? 4 : (kn.part_waves == 8 && in.dp % 64 == 0 ? 8 : g.waves);
+        const int per_cu = two ? 2 : 1, simd_waves = two ? 2 : pw / 4;
         const int64_t most = (strips + pw - 1) / pw;
         // the split with the fewest units on the busiest wave; among equals the fewest K parts
         // (longer rounds, fewer partial stores per step: 40 000 rows 237 us as 64 x 4 or 128 x 2, 245 as 32 x 8)
         int64_t best_u = INT64_MAX, bg = 0, bk = 0;
         for (int64_t k = 1; k <= g.nchunks; ++k) {
-            int64_t groups = std::min<int64_t>(in.cus / k, most);
+            int64_t groups = std::min<int64_t>((int64_t)in.cus * per_cu / k, most);
             if (groups < 1) continue;
             const int64_t spb = (strips + groups - 1) / groups;
             const int64_t spw = (spb + pw - 1) / pw;
             const int64_t cpb = (g.nchunks + k - 1) / k;
-            // units per SIMD: the waves of a SIMD (pw / 4) take spw strips at most each
-            if (spw * cpb * (pw / 4) < best_u) {
-                best_u = spw * cpb * (pw / 4);
+            // units per SIMD: the waves of a SIMD take spw strips at most each
+            if (spw * cpb * simd_waves < best_u) {
+                best_u = spw * cpb * simd_waves;
                 bg = groups;
                 bk = k;
             }
@@ -172,13 +184,14 @@ inline MqPlan mq_plan_compute(const MqPlanIn& in, const MqPlanKnobs& kn) {
             const int64_t spb = (g.tail_strips + g.tail_groups - 1) / g.tail_groups;
             tail_units = ((spb + g.waves - 1) / g.waves) * ((g.nchunks + g.tail_ks - 1) / g.tail_ks);
         }
-        if (bg > 0 && (best_u <= q_units + tail_units + (pw == 8 ? 1 : 0) || kn.allpart == 2)) {
+        if (bg > 0 && (best_u <= q_units + tail_units + (simd_waves == 2 ? 1 : 0) || kn.allpart == 2)) {
             g.n_main = 0;
             g.tail_strips = strips;
             g.tail_groups = (int)bg;
             g.tail_ks = (int)bk;
             g.part_waves = pw;
-            if (pw == 8) g.part_kw = 64;
+            g.part_per_cu = per_cu;
+            if (pw == 8 || two) g.part_kw = 64;
         }
     }
     const int64_t strips_main = (g.n_main + 15) / 16;

@@ -72,8 +72,13 @@ __device__ inline void mq_store_partial(f32x4* dst, const f32x4& v) {
 #endif
 }
 
+// (two waves per SIMD - at most 256 registers per wave - for the form that runs as two four-wave blocks per CU)
+template <int KW, int NST, int MODE, int NW>
+constexpr int mq_min_waves_per_simd() {
+    return MODE == MODE_PART && NW == 4 && NST == 2 && KW == 64 ? 2 : 1;
+}
 template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void k_scan_mq(const MqArgs A) {
+__global__ __launch_bounds__(NW * 64, (mq_min_waves_per_simd<KW, NST, MODE, NW>())) void k_scan_mq(const MqArgs A) {
     using GM = DmaGeom<KW>;
     constexpr int R = GM::R, NB = GM::NB, kPiece = GM::kPiece;
     constexpr int NP = 16 / R;            // DMA pieces per 16-row stage (== NB)
@@ -670,15 +675,15 @@ __global__ __launch_bounds__(256) void k_mq_combine(const MqArgs A, int tiles, i
     }
 }
 
-// LDS bytes of a variant
-template <int T, int KW, int NST, int NW>
+// LDS bytes of a variant (K-split mode has no epilogue: no area for the row / query norms)
+template <int T, int KW, int NST, int NW, int MODE>
 constexpr size_t mq_lds_bytes() {
-    return (size_t)(NW * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece + (size_t)NW * 1024;   // + row norms, query norms
+    return (size_t)(NW * NST + 2 * T) * (16 / DmaGeom<KW>::R) * DmaGeom<KW>::kPiece + (MODE == MODE_PART ? 0 : (size_t)NW * 1024);
 }
 
 template <int T, int KW, int NST, int NS, int AUX, int MODE, int NW>
 int launch_one(const MqArgs& a, hipStream_t st) {
-    constexpr size_t lds = mq_lds_bytes<T, KW, NST, NW>();
+    constexpr size_t lds = mq_lds_bytes<T, KW, NST, NW, MODE>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set[64] = {};
     if (!attr_set[a.device & 63]) {
@@ -746,6 +751,26 @@ int launch_scan_mq(const MqArgs& a, int tiles, int kw, int waves, int mode, bool
             case 3: return launch_one<3, 64, 3, 8, 0, MODE_PART, 8>(a, st);
             case 4: return launch_one<4, 64, 3, 6, 0, MODE_PART, 8>(a, st);
             default: return launch_one<5, 64, 3, 6, 0, MODE_PART, 8>(a, st);
+        }
+    }
+    // ... and as TWO four-wave blocks per CU (A/B, CSLAM_MQ_PART_BLOCKS2): rings of two 4-KiB stages, 78 KiB of LDS
+    // per block at five tiles, <= 256 registers per wave - a block's barrier is covered by the other block's MFMAs
+    if (mode == kMqModePart && a.part_per_cu == 2 && waves == 4 && kw == 64 && tiles >= 2 && tiles <= 5 && a.dp % 64 == 0 &&
+        a.n > 0 && a.n_blocks >= 1) {
+        static_assert(2 * mq_lds_bytes<5, 64, 2, 4, MODE_PART>() <= 160 * 1024, "two blocks per CU");
+        if (nt) {
+            switch (tiles) {
+                case 2: return launch_one<2, 64, 2, 8, 2, MODE_PART, 4>(a, st);
+                case 3: return launch_one<3, 64, 2, 8, 2, MODE_PART, 4>(a, st);
+                case 4: return launch_one<4, 64, 2, 6, 2, MODE_PART, 4>(a, st);
+                default: return launch_one<5, 64, 2, 6, 2, MODE_PART, 4>(a, st);
+            }
+        }
+        switch (tiles) {
+            case 2: return launch_one<2, 64, 2, 8, 0, MODE_PART, 4>(a, st);
+            case 3: return launch_one<3, 64, 2, 8, 0, MODE_PART, 4>(a, st);
+            case 4: return launch_one<4, 64, 2, 6, 0, MODE_PART, 4>(a, st);
+            default: return launch_one<5, 64, 2, 6, 0, MODE_PART, 4>(a, st);
         }
     }
     if (tiles < 2 || tiles > 5 || (kw != 128 && kw != 64) || a.dp % kw != 0 || a.n <= 0 || a.n_blocks < 1 ||

@@ -29,6 +29,7 @@ struct MqArgs {
     uint64_t* cand_c;
     f32x4* part;           // K-split mode: [strip][chunks][tiles][64] chunk partials (chunk = 512 floats)
     int part_ks;           // K-split mode: K parts per strip group (grid = n_blocks x part_ks)
+    int part_per_cu;       // K-split mode: 2 = the two-blocks-per-CU form (four waves, rings of two 64-float stages)
 };
 
 constexpr int kMqModeDots = 0, kMqModeBest = 1, kMqModePart = 2;

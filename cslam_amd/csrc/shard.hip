@@ -22,7 +22,6 @@
 
 #include "common.hpp"
 #include "composite.hpp"
-#include "mq_combine.hpp"
 #include "topk_parts.hpp"
 
 using namespace cslam;
@@ -246,17 +245,6 @@ __global__ __launch_bounds__(256) void k_records_from_candidates(
     if (threadIdx.x != 0) return;
     records_of_descriptor(R, i, ba, bc);
 }
-// (round 5) ... and as the tail of the multi-tile scan's fused fold + final level (mq_combine.hpp): where the
-// whole window of the pool went through the K-split launch, thread i of k_mq_combine_final's last block writes
-// descriptor i's record slots - no launch of its own behind the combine
-struct RecordsFinal {
-    RecordArgs R;
-    __device__ void operator()(int i, uint64_t ba, uint64_t bc) const { records_of_descriptor(R, i, ba, bc); }
-};
-int launch_records_final(const MqArgs& a, int tiles, int nchunks, const MqFinalScratch& fs, void* ctx, hipStream_t st) {
-    return launch_mq_combine_final(a, tiles, nchunks, fs, *static_cast<const RecordsFinal*>(ctx), nullptr, 0u, st);
-}
-
 // The gathered exchange buffer holds, per rank, [b_max][dim] fp32 rows followed by the (count,
 // keyframe ids) header: ONE all-gather per step instead of two.  This kernel copies the rows to the
 // dense [R * b_max][dim] block the scan reads its queries from and the headers to all_meta.
@@ -608,16 +596,13 @@ int cslam_shard_match(cslam_shard_t* sh, void* stream) {
         // ONE scan launch: best row before n0 and best row of the new block per gathered
         // descriptor; its candidates are reduced by the record kernel itself
         BestCandidates bc;
-        bool applied = false, records_done = false;
-        RecordsFinal rfin{{me, R, bm, s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, my_recs}};
-        const MqFinalHook hook{launch_records_final, &rfin};
+        bool applied = false;
+        const RecordArgs rargs{me, R, bm, s.all_meta, n0, sh->kf_of_row, s.b, sh->thr, my_recs};
         CSLAM_TRY(pool_best_split_candidates(sh->pool, s.all_rows, dim, M, n0, hi, st, &bc, &applied,
                                              s.staged_valid ? s.staged : nullptr,
-                                             s.staged_valid ? s.staged_rnq : nullptr, &hook, &records_done));
-        if (applied && records_done) {
-            // (the scan's fused final level wrote the records)
-        } else if (applied) {
-            hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, rfin.R, bc.a, bc.c, bc.stride,
+                                             s.staged_valid ? s.staged_rnq : nullptr));
+        if (applied) {
+            hipLaunchKernelGGL(k_records_from_candidates, dim3(M), dim3(256), 0, st, rargs, bc.a, bc.c, bc.stride,
                                bc.n);
         } else {
             CSLAM_TRY(ensure_rows());

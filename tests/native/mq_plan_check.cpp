@@ -24,7 +24,8 @@ static void invariants(const MqPlanIn& in, const MqPlanKnobs& kn, const MqPlan& 
     if (g.tail_strips > 0) {
         EXPECT(g.n_main % 16 == 0, T_);                                            // the tail starts on a strip boundary
         EXPECT(g.tail_groups >= 1 && g.tail_ks >= 1 && g.tail_ks <= g.nchunks, T_);
-        EXPECT((int64_t)g.tail_groups * g.tail_ks <= in.cus || kn.tail_shape == 2 || g.n_main > 0, T_);   // one wave of blocks
+        EXPECT((int64_t)g.tail_groups * g.tail_ks <= (int64_t)in.cus * g.part_per_cu || kn.tail_shape == 2 || g.n_main > 0, T_);   // one wave of blocks
+        EXPECT(g.part_per_cu == 1 || (g.part_per_cu == 2 && g.part_waves == 4 && g.part_kw == 64 && g.n_main == 0 && in.dp % 64 == 0), T_);
         EXPECT(g.tail_groups <= g.tail_strips, T_);
         EXPECT((g.part_waves == 4 || g.part_waves == 8) && (g.part_kw == 64 || g.part_kw == g.kw), T_);
         if (g.part_waves == 8) EXPECT(g.part_kw == 64 && in.dp % 64 == 0, T_);
@@ -55,7 +56,7 @@ int main() {
                         MqPlanIn in{vn, dp, cus, dp + (dp * 4 % 4096 == 0 ? 128 : 0), m, shard != 0, false};
                         invariants(in, def, mq_plan_compute(in, def));
                         ++cases;
-                        for (int variant = 0; variant < 6; ++variant) {
+                        for (int variant = 0; variant < 7; ++variant) {
                             MqPlanKnobs kn;
                             if (variant == 0) kn.tail = 0;
                             if (variant == 1) kn.allpart = 0;
@@ -63,6 +64,7 @@ int main() {
                             if (variant == 3) { kn.allpart = 0; kn.tail_shape = 2; }
                             if (variant == 4) kn.part_waves = 4;
                             if (variant == 5) { kn.kw = 64; kn.pack_blocks = 0; }
+                            if (variant == 6) kn.part_blocks2 = 0;
                             const MqPlan g = mq_plan_compute(in, kn);
                             invariants(in, kn, g);
                             if (variant == 0) EXPECT(g.tail_strips == 0 && g.n_main == vn, "CSLAM_MQ_TAIL=0 keeps one launch");
@@ -77,14 +79,22 @@ int main() {
         MqPlanIn in{vn, dp, 256, dp + (dp * 4 % 4096 == 0 ? 128 : 0), m, shard, false};
         return mq_plan_compute(in, def);
     };
-    {   // cfg4: 25 000 rows x 80 gathered descriptors: the whole window through the K-split launch, 32 groups x 8 K parts
+    {   // cfg4: 25 000 rows x 80 gathered descriptors: the whole window through the K-split launch, 64 groups x 8 K parts
+        // of four-wave blocks, two per CU (round 4: 32 x 8 eight-wave blocks)
         const MqPlan g = plan(25000, 4096, 80, true);
-        EXPECT(g.n_main == 0 && g.tail_strips == 1563 && g.tail_groups == 32 && g.tail_ks == 8 && g.part_waves == 8 && g.part_kw == 64,
-               "cfg4 plan: n_main %lld, %d x %d, %d waves", (long long)g.n_main, g.tail_groups, g.tail_ks, g.part_waves);
+        EXPECT(g.n_main == 0 && g.tail_strips == 1563 && g.tail_groups == 64 && g.tail_ks == 8 && g.part_waves == 4 && g.part_kw == 64 &&
+                   g.part_per_cu == 2,
+               "cfg4 plan: n_main %lld, %d x %d, %d waves, %d per CU", (long long)g.n_main, g.tail_groups, g.tail_ks, g.part_waves, g.part_per_cu);
+        MqPlanKnobs r4;
+        r4.part_blocks2 = 0;
+        MqPlanIn in{25000, 4096, 256, 4096 + 128, 80, true, false};
+        const MqPlan g4 = mq_plan_compute(in, r4);
+        EXPECT(g4.n_main == 0 && g4.tail_groups == 32 && g4.tail_ks == 8 && g4.part_waves == 8 && g4.part_kw == 64 && g4.part_per_cu == 1,
+               "cfg4 plan, one eight-wave block per CU: %d x %d, %d waves", g4.tail_groups, g4.tail_ks, g4.part_waves);
     }
-    {   // 40 000 rows (2500 strips): 64 groups x 4 K parts - 20 units on the busiest SIMD (32 x 8 has 20 too: the fewer K parts win)
+    {   // 40 000 rows (2500 strips): 128 groups x 4 K parts - 20 units on the busiest SIMD (64 x 8 has 20 too: the fewer K parts win)
         const MqPlan g = plan(40000, 4096, 80);
-        EXPECT(g.n_main == 0 && g.tail_groups == 64 && g.tail_ks == 4, "40 000-row plan: n_main %lld, %d x %d", (long long)g.n_main,
+        EXPECT(g.n_main == 0 && g.tail_groups == 128 && g.tail_ks == 4 && g.part_per_cu == 2, "40 000-row plan: n_main %lld, %d x %d", (long long)g.n_main,
                g.tail_groups, g.tail_ks);
     }
     {   // 100 000 rows: every wave exactly six strips in the main launch, 106 strips in the K-split tail

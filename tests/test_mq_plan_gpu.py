@@ -62,7 +62,7 @@ def test_every_form_of_the_pass_gives_the_same_bits(gpu, knobs, n, d, m, k):
     kk = int(o_cnt[0])
     seen = set()
     for env in ({}, {"CSLAM_MQ_ALLPART": "0"}, {"CSLAM_MQ_ALLPART": "2"}, {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_PART_WAVES": "4"},
-                {"CSLAM_MQ_ALLPART": "0", "CSLAM_MQ_TAIL_SHAPE": "2"}, {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_FINAL": "0"}):
+                {"CSLAM_MQ_ALLPART": "0", "CSLAM_MQ_TAIL_SHAPE": "2"}, {"CSLAM_MQ_ALLPART": "2", "CSLAM_MQ_PART_BLOCKS2": "0"}):
         knobs.only(env)
         p = _pool(X)
         rows, sims = p.search_batch(Q, k)
@@ -149,11 +149,10 @@ def test_pools_of_60000_then_12000_rows_in_one_process_under_alternating_plans(g
         del Xd, Qd, idx, sim
 
 
-def test_fused_final_level_of_the_k_split_pass(gpu, knobs):
-    """Where the whole window goes through the K-split launch, search_best ends in ONE launch behind it: fold, epilogue
-    and final level (k_mq_combine_final, csrc/mq_combine.hpp) - atomic maxima of the strips' composites + a ticket -
-    instead of k_mq_combine + k_best_pair.  Same bits as the two-launch form and as the oracle; the scratch cleans
-    itself: query counts going down and up on one pool, the split search in between, ties -> lowest row."""
+def test_both_forms_of_the_k_split_launch_on_one_pool(gpu, knobs):
+    """The whole window through the K-split launch as two four-wave blocks per CU (round 5, default) and as one
+    eight-wave block (round 4, CSLAM_MQ_PART_BLOCKS2=0): same bits as the oracle, query counts going down and up
+    on one pool, the split search in between, ties -> lowest row."""
     import torch
     from cslam_amd import _lib
     n, d = 25000, 512
@@ -162,31 +161,31 @@ def test_fused_final_level_of_the_k_split_pass(gpu, knobs):
     p = _pool(X)
     qd = torch.from_numpy(Q).cuda()
     o_idx, o_sim, _ = oracle_knn.search(X, Q, 1)
-    for m in (80, 33, 48, 80, 17):
-        rows, sims = p.search_batch(Q[:m], 1)
-        name = gpu.cslam_pool_scan_kernel(p.handle).decode()
-        assert (name.endswith("k_mq_combine_final")) == (m > 32), (m, name)   # two tiles never take the all-K-split form
-        np.testing.assert_array_equal(rows, o_idx[:m, :1])
-        assert sims.tobytes() == o_sim[:m, :1].astype(np.float32).tobytes()
-        assert m <= 7 or rows[7, 0] == 5
-        if m == 48:   # the split search through the same launch, then back
-            split = 16 * 700 + 5
-            ia = torch.empty(m, dtype=torch.int32, device="cuda"); sa = torch.empty(m, device="cuda")
-            ic = torch.empty(m, dtype=torch.int32, device="cuda"); sc = torch.empty(m, device="cuda")
-            _lib.check(gpu.cslam_pool_search_best_split_dev(p.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split, n,
-                                                            ctypes.c_void_p(ia.data_ptr()), ctypes.c_void_p(sa.data_ptr()),
-                                                            ctypes.c_void_p(ic.data_ptr()), ctypes.c_void_p(sc.data_ptr()), None))
-            torch.cuda.synchronize()
-            assert gpu.cslam_pool_scan_kernel(p.handle).decode().endswith("k_mq_combine_final")
-            oa, osa, _ = oracle_knn.search(X[:split], Q[:m], 1)
-            oc, osc, _ = oracle_knn.search(X[split:], Q[:m], 1)
-            np.testing.assert_array_equal(ia.cpu().numpy(), oa[:, 0])
-            assert sa.cpu().numpy().tobytes() == osa[:, 0].astype(np.float32).tobytes()
-            np.testing.assert_array_equal(ic.cpu().numpy(), oc[:, 0] + split)
-            assert sc.cpu().numpy().tobytes() == osc[:, 0].astype(np.float32).tobytes()
-    knobs.set("CSLAM_MQ_FINAL", "0")
-    rows2, sims2 = p.search_batch(Q, 1)
-    assert gpu.cslam_pool_scan_kernel(p.handle).decode().endswith("k_mq_combine<best>")
-    np.testing.assert_array_equal(rows2, o_idx[:, :1])
-    assert sims2.tobytes() == o_sim[:, :1].astype(np.float32).tobytes()
+    names = set()
+    for blocks2 in ("1", "0"):
+        knobs.set("CSLAM_MQ_PART_BLOCKS2", blocks2)
+        for m in (80, 33, 48, 80, 17):
+            rows, sims = p.search_batch(Q[:m], 1)
+            name = gpu.cslam_pool_scan_kernel(p.handle).decode()
+            assert ("part>" in name) == (m > 32), (m, name)   # two tiles never take the all-K-split form
+            if m > 32:
+                names.add(name)
+            np.testing.assert_array_equal(rows, o_idx[:m, :1])
+            assert sims.tobytes() == o_sim[:m, :1].astype(np.float32).tobytes()
+            assert m <= 7 or rows[7, 0] == 5
+            if m == 48:   # the split search through the same launch, then back
+                split = 16 * 700 + 5
+                ia = torch.empty(m, dtype=torch.int32, device="cuda"); sa = torch.empty(m, device="cuda")
+                ic = torch.empty(m, dtype=torch.int32, device="cuda"); sc = torch.empty(m, device="cuda")
+                _lib.check(gpu.cslam_pool_search_best_split_dev(p.handle, ctypes.c_void_p(qd.data_ptr()), d, m, split, n,
+                                                                ctypes.c_void_p(ia.data_ptr()), ctypes.c_void_p(sa.data_ptr()),
+                                                                ctypes.c_void_p(ic.data_ptr()), ctypes.c_void_p(sc.data_ptr()), None))
+                torch.cuda.synchronize()
+                oa, osa, _ = oracle_knn.search(X[:split], Q[:m], 1)
+                oc, osc, _ = oracle_knn.search(X[split:], Q[:m], 1)
+                np.testing.assert_array_equal(ia.cpu().numpy(), oa[:, 0])
+                assert sa.cpu().numpy().tobytes() == osa[:, 0].astype(np.float32).tobytes()
+                np.testing.assert_array_equal(ic.cpu().numpy(), oc[:, 0] + split)
+                assert sc.cpu().numpy().tobytes() == osc[:, 0].astype(np.float32).tobytes()
+    assert any("2 per CU" in x for x in names) and any("NW=8" in x for x in names), names
     p.close()
