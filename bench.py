@@ -463,7 +463,7 @@ def main():
     # the kernel variant and the shape that ran here - `traffic_source` says where it came from
     traffic, traffic_source = None, None
     mfma_busy = None
-    for name in ("r04_scan_pmc.json", "r04_mq_pmc.json", "r03_scan_pmc.json", "r02_scan_pmc.json"):
+    for name in ("r05_scan_pmc.json", "r05_mq_pmc.json", "r04_scan_pmc.json", "r04_mq_pmc.json", "r03_scan_pmc.json", "r02_scan_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc):
             continue

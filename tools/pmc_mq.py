@@ -2,7 +2,7 @@
 from rocprofv3 --pmc passes (tools/pmc_cfg4.sh):
   pass 1: SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES   (matrix-pipe busy, clock)
   pass 5: FETCH_SIZE    pass 6: WRITE_SIZE                                          (HBM traffic; FETCH x2 on gfx950)
-Round 4: the pass is the K-split launch k_scan_mq<5, 64, 3, 6, 0, 2, 8> + k_mq_combine<true>; both are summed.
+The pass is the K-split launch (round 4: k_scan_mq<5, 64, 3, 6, 0, 2, 8>, round 5: <5, 64, 2, 6, 2, 2, 4>, two blocks per CU) + k_mq_combine<true>; both are summed.
 usage: pmc_mq.py mfma_dir fetch_dir write_dir "<roofline.kernel of the bench line>" out.json"""
 import csv, glob, json, os, statistics, sys
 
