@@ -710,6 +710,25 @@ def cpu_baseline(torch, X, queries, gpu_idx, gpu_sim):
            "note": "strict fmaf chain of the numeric contract (cannot vectorise); the reference's "
                    "own torch-CPU search of the same pool measured 1.1 queries/s on 8 cores "
                    "(BASELINE.md, build container)"}
+    # ... and the reference's own per-query arithmetic with BLAS-backed numpy in place of its torch-CPU calls
+    # (oracle.knn.search_numpy: cosine_similarity over the whole pool, norms recomputed per call, full argsort -
+    # cslam/nns_matching.py:57-63), 4 queries one by one against the same sample, all host cores BLAS gives it
+    try:
+        nq = min(4, q.shape[0])
+        oracle_knn.search_numpy(xs[:1000], q[0], 1)
+        t0 = time.perf_counter()
+        same = 0
+        for j in range(nq):
+            ii, ss = oracle_knn.search_numpy(xs, q[j], 1)
+            same += int(ii[0] == idx[j, 0])
+        dt2 = time.perf_counter() - t0
+        out["numpy_path"] = {"value": nq / (dt2 * X.shape[0] / rows), "unit": "candidates/s",
+                             "sample": f"{nq} queries, one call each, x {rows} of {X.shape[0]} rows; {dt2:.2f} s measured, scaled "
+                                       f"x{X.shape[0] / rows:.1f}; best row equal to the port's in {same} of {nq}",
+                             "what": "the reference's per-query search with numpy + BLAS for its torch-CPU calls (sgemv, row norms "
+                                     "recomputed per call, full argsort): the CPU path a user of the reference runs"}
+    except Exception as e:
+        out["numpy_path"] = {"error": repr(e)}
     # second half of the metric: one Fiedler solve of the cfg3 graph on the CPU path the reference
     # uses (networkx TraceMIN + SuperLU, restated in oracle/mac_oracle.py; single-threaded scipy)
     try:

@@ -88,3 +88,21 @@ def search(rows, queries, k):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def search_numpy(rows, query, k, eps=1e-8):
+    """The reference's OWN per-query arithmetic with BLAS-backed numpy in place of its torch-CPU calls
+    (cslam/nns_matching.py:57-63: `cosine_similarity(view, q)` over the whole pool - the row norms are
+    recomputed at every call, as there - then a full descending `argsort`, first k).  Not the numeric
+    contract of the HIP path (that is knn_oracle.c's pinned summation order): this is the CPU path a user
+    of the reference runs, timed by bench.py's cpu_baseline beside the strict-chain port, and pinned to
+    the same goldens within the reference's 1e-6 (tests/test_oracle_knn.py).
+    Returns (idx[k] int64, sim[k] float32)."""
+    rows = _f32(rows, 2)
+    q = _f32(np.asarray(query).reshape(-1), 1)
+    dots = rows @ q                                                  # sgemv
+    xn = np.sqrt(np.einsum("ij,ij->i", rows, rows))                  # a second pass over the pool, per call
+    qn = np.sqrt(np.dot(q, q))
+    sims = (dots / np.maximum(xn, eps)) / max(float(qn), eps)        # torch >= 1.12: each norm clamped by eps
+    order = np.argsort(-sims, kind="stable")[:k]
+    return order, sims[order].astype(np.float32)

@@ -64,3 +64,17 @@ def test_euclidean_order_property():
         for j in range(100):
             if nd[j] != idx[0, j]:
                 assert abs(ds[nd[j]] - ds[idx[0, j]]) < 1e-6
+
+
+@pytest.mark.parametrize("case", [str(c) for c in G["cases"]])
+def test_numpy_restatement_of_the_reference_path_matches_reference(case):
+    """oracle.knn.search_numpy (what bench.py times as the reference-like CPU path) against the same goldens."""
+    X, Q, ref_idx, ref_sim, k = (G[f"{case}_{s}"] for s in ("X", "Q", "idx", "sim", "k"))
+    kk = min(int(k), X.shape[0])
+    all_sims = oracle_knn.similarities(X, Q)
+    for q in range(Q.shape[0]):
+        idx, sim = oracle_knn.search_numpy(X, Q[q], int(k))
+        np.testing.assert_allclose(sim[:kk], ref_sim[q, :kk], atol=1e-6, rtol=0)
+        for j in range(kk):
+            if idx[j] != ref_idx[q, j]:
+                assert abs(all_sims[q, idx[j]] - all_sims[q, ref_idx[q, j]]) <= 2e-6, (case, q, j)
