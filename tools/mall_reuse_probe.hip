@@ -28,6 +28,7 @@ struct Order {
     int chunk[16];
     int n;        // chunks per row
     int keep;     // chunk read with the default policy (-1: none)
+    int keep_lo, keep_hi;   // ... or the slices [keep_lo, keep_hi) (part 2 of the probe: a FIXED resident set, no reorder)
 };
 
 __global__ __launch_bounds__(NW * 64) void k_stream(const float* __restrict__ X, int64_t xs, int64_t n, Order o,
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(NW * 64) void k_stream(const float* __restrict__ X,
     const int64_t s_lo = strips * w / total_waves, s_hi = strips * (w + 1) / total_waves;
     for (int ci = 0; ci < o.n; ++ci) {
         const int c = o.chunk[ci];
-        const bool keep = c == o.keep;
-        for (int kc = 2 * c; kc < 2 * c + 2; ++kc)          // a chunk = two 256-float slices
+        for (int kc = 2 * c; kc < 2 * c + 2; ++kc) {        // a chunk = two 256-float slices
+            const bool keep = c == o.keep || (kc >= o.keep_lo && kc < o.keep_hi);
             for (int64_t s = s_lo; s < s_hi; ++s) stage(s, kc, keep);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (sink && lane == 0 && w == 0) sink[0] = *reinterpret_cast<float*>(ring);
@@ -77,6 +79,7 @@ static Order make(int first, int keep, int nch) {   // first < 0: in order
     Order o{};
     o.n = nch;
     o.keep = keep;
+    o.keep_lo = o.keep_hi = 0;
     int k = 0;
     if (first >= 0) o.chunk[k++] = first;
     for (int c = 0; c < nch; ++c)
@@ -128,6 +131,37 @@ int main(int argc, char** argv) {
     };
     printf("n=%lld dp=%d cus=%d: pool %.0f MB, one chunk of every row %.0f MB\n", (long long)n, dp, cus, n * dp * 4 / 1e6,
            n * 512 * 4 / 1e6);
+    // part 2: no reorder at all - a FIXED set of slices is always read with the default policy, everything else
+    // non-temporal (non-temporal reads do not allocate: does the fixed set stay resident from launch to launch?)
+    auto run_fixed = [&](int lo, int hi) {
+        Order o = make(-1, -1, nch);
+        o.keep_lo = lo;
+        o.keep_hi = hi;
+        for (int t = 0; t < 10; ++t)
+            hipLaunchKernelGGL(k_stream, dim3(cus), dim3(NW * 64), lds, 0, X, xs, n, o, total_waves, sink);
+        CK(hipDeviceSynchronize());
+        const int reps = 40;
+        CK(hipEventRecord(e0, 0));
+        for (int t = 0; t < reps; ++t)
+            hipLaunchKernelGGL(k_stream, dim3(cus), dim3(NW * 64), lds, 0, X, xs, n, o, total_waves, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double per = ms / reps;
+        printf("fixed set: slices [%2d, %2d) of 16 with the default policy (%4.0f MB)    %.4f ms per launch  %.0f GB/s\n", lo, hi,
+               (hi - lo) * n * 1024.0 / 1e6, per, (double)n * dp * 4 / (per * 1e-3) / 1e9);
+    };
+    for (int rep = 0; rep < 2; ++rep) {
+        run_fixed(0, 0);
+        run_fixed(15, 16);
+        run_fixed(14, 16);
+        run_fixed(13, 16);
+        run_fixed(12, 16);
+        run_fixed(0, 2);
+        run_fixed(7, 9);
+        run_fixed(0, 16);
+    }
     for (int rep = 0; rep < 3; ++rep) {
         run("(a) in order, non-temporal", 0);
         run("(b) last chunk kept (default policy), next launch starts with it", 1);
