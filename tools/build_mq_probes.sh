@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing probes of k_scan_mq: the library with one ingredient of the stage loop compiled out
-# (results are wrong; time only).  Output: tools/probe_libs/libcslam_hip_<name>.so, loaded by
+# (results are wrong; time only) - and PROBES=AUDIT: the address audit (tools/probes/mq_probe_audit.hpp: results
+# are the product's, every global address is checked before use; tools/mq_audit.py).  Output: tools/probe_libs/libcslam_hip_<name>.so, loaded by
 # tools/mq_time.py through CSLAM_PROBE_LIB.
 set -e
 cd "$(dirname "$0")/../cslam_amd/csrc"
