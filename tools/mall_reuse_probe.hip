@@ -152,6 +152,11 @@ int main(int argc, char** argv) {
         printf("fixed set: slices [%2d, %2d) of 16 with the default policy (%4.0f MB)    %.4f ms per launch  %.0f GB/s\n", lo, hi,
                (hi - lo) * n * 1024.0 / 1e6, per, (double)n * dp * 4 / (per * 1e-3) / 1e9);
     };
+    if (argc > 2) {   // part 3: a mid-size pool - how much of it should stay resident?
+        for (int rep = 0; rep < 2; ++rep)
+            for (int hi = 0; hi <= 16; hi += 2) run_fixed(0, hi);
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run_fixed(0, 0);
         run_fixed(15, 16);
